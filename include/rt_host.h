@@ -1,0 +1,84 @@
+/*
+ * rt_host.h -- C ABI of librt_host.so: the host-side mirror of the reference's
+ * scene-setup API, i.e. the code that stays on the CPU and FEEDS the trace/shade
+ * path: Materials.hs, Objects.hs, BenchmarkScene*.hs, sahBVH
+ * (BoundingVolumeHierarchy.hs:34-94), configToWorld/getCam (Main.hs:104-126),
+ * generateGrids (RayTracer.hs:462-475) and writePPM (Main.hs:128-138).
+ *
+ * In a deployment the Haskell host does all of this itself; this
+ * library exists because there is no GHC in the build image, so the harness,
+ * the tests and bench.py need a native producer of the same inputs.  No GPU code.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* `Config` (src/Main.hs:50-62) minus cScene. */
+typedef struct rth_config {
+  int32_t image_w, image_h;
+  int32_t view_w, view_h, view_d;
+  int32_t reflection_depth;
+  int32_t anti_aliasing;        /* rays per pixel; wAntiAliasing = floor(sqrt) */
+  float lens;
+  float up[3], eye[3], look_at[3];
+} rth_config;
+
+typedef struct rth_scene rth_scene;
+
+/* Built-in scenes: "bench1".."bench5" (src/BenchmarkScene*.hs with their lights),
+ * "kat_tris" (benchmarks/Main.hs:10-13), "mesh:<n>" = generated station-style
+ * triangle mesh of about n triangles with the 8 point lights of bench6World
+ * (src/Main.hs:239-246).  Returns NULL for an unknown name. */
+rth_scene *rth_scene_builtin(const char *name);
+
+/* Scene from caller-provided objects.  `order` lists the objects in [Object]
+ * list order (leaf_refs encoding: RT_REF_TRIANGLE | index, or sphere index);
+ * object_id fields are overwritten with the list position. */
+rth_scene *rth_scene_create(const rt_sphere *spheres, int32_t n_spheres,
+                            const rt_triangle *triangles, int32_t n_triangles,
+                            const uint32_t *order, int32_t n_objects,
+                            const rt_material *materials, int32_t n_materials,
+                            const rt_light *lights, int32_t n_lights);
+void rth_scene_free(rth_scene *s);
+
+/* Build the tree.  builder 0 = sahBVH (BoundingVolumeHierarchy.hs:34-51),
+ * 1 = noBVH (one leaf with every object, BoundingVolumeHierarchy.hs:130-131). */
+int rth_scene_build_bvh(rth_scene *s, int builder);
+
+/* Borrowed view (valid until the scene is freed or rebuilt). */
+int rth_scene_view(const rth_scene *s, rt_scene *out);
+int32_t rth_scene_n_objects(const rth_scene *s);
+int32_t rth_scene_bvh_depth(const rth_scene *s);
+
+/* benchNConfig (src/Main.hs:151-235): "bench1".."bench6". */
+int rth_default_config(const char *name, rth_config *out);
+
+/* configToWorld + getCam (src/Main.hs:104-126), scalar part. */
+int rth_config_to_camera(const rth_config *cfg, rt_camera *out);
+
+/* Sample table with the structure of generateGrids/getGrids/getGridR
+ * (src/RayTracer.hs:462-475, 215-222): n_grids x aa*aa x F6.  out holds
+ * n_grids*aa*aa*6 floats.  The random stream is OURS (MT19937-64 seeded with
+ * `seed`), not the reference's unpinned package stack. */
+int rth_generate_grids(uint64_t seed, int32_t n_grids, int32_t aa, float *out);
+
+/* writePPM (src/Main.hs:128-138) and its 8-bit quantisation. */
+int rth_write_ppm(const char *path, int32_t w, int32_t h, const float *rgb);
+void rth_quantize(const float *rgb, size_t n, uint8_t *out);
+
+/* Material table of Materials.hs by name ("whiteDull", "glass", ...). */
+int rth_material_by_name(const char *name, rt_material *out);
+
+/* makeTriangle / calcNormal (src/Objects.hs:13-19). */
+void rth_make_triangle(const float a[3], const float b[3], const float c[3], int32_t material,
+                       rt_triangle *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,231 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X trace/shade library (librt_mi355x.so).
+ *
+ * This is the drop-in boundary for ONE path of jrraymond/ray-tracer: everything
+ * that happens underneath
+ *
+ *     render :: PureMT -> World -> [Color]              (src/RayTracer.hs:18-23)
+ *
+ * i.e. colorPixel / getRay / raytrace / hitBVH / hits / hit / hitsBox /
+ * getDirectColor / inShadow / getIndirectColor / reflect / refract / orthonormal
+ * / avgColors.  The reference has no FFI of its own (it is pure Haskell); this
+ * header is what a `foreign import ccall safe` shim placed under `render` binds
+ * (see INTEGRATION.md for the Haskell side).  The Haskell host keeps building
+ * the scene, the SAH BVH (src/BoundingVolumeHierarchy.hs:34-51) and the sample
+ * grids (src/RayTracer.hs:462-475); it flattens them into the PODs below.
+ *
+ * Conventions: plain C, no torch types; every call returns 0 on success or a
+ * negative rt_status; nothing throws or aborts across the boundary; the library
+ * copies host inputs on upload and never keeps a host pointer; all outputs are
+ * caller-allocated.  A context is bound to one GPU, is not thread-safe, and all
+ * calls are synchronous unless the name ends in _async.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,   /* bad argument / inconsistent scene              */
+  RT_ERR_STATE = -2,     /* call order (render before upload, ...)         */
+  RT_ERR_DEVICE = -3,    /* HIP runtime error (text in rt_last_error)      */
+  RT_ERR_LIMIT = -4,     /* a stated limit exceeded (tree depth, sizes...) */
+  RT_ERR_NOMEM = -5
+} rt_status;
+
+/* ---- scene PODs ------------------------------------------------------- */
+
+/* One BVH tree node.  Mirrors `data BVH = Node !BVH !BVH !Box | Leaf ![Object] !Box`
+ * (src/Types.hs:97-100); the six floats are the fields of `Box` in declaration
+ * order (src/Types.hs:88-93).
+ *   inner node: left >= 0 and right >= 0 are node indices.
+ *   leaf      : left  = -1 - first   (first = offset into leaf_refs)
+ *               right = count        (>= 1; the leaf's object list, in list order)
+ * Node 0 is the root.  `Empty` (src/Types.hs:99) is n_nodes == 0. */
+typedef struct rt_bvh_node {
+  float xmin, xmax, ymin, ymax, zmin, zmax;
+  int32_t left, right;
+} rt_bvh_node;
+
+/* leaf_refs entry: bit 31 set = triangle, clear = sphere; low 31 bits = index
+ * into the triangle / sphere array. */
+#define RT_REF_TRIANGLE 0x80000000u
+#define RT_REF_INDEX(r) ((r) & 0x7fffffffu)
+
+/* `Sphere pos rad mat` (src/Types.hs:74-76).  object_id = position of the object in
+ * the host's [Object] list; it is what primary_hit_ids reports. */
+typedef struct rt_sphere {
+  float center[3];
+  float radius;
+  int32_t material;
+  int32_t object_id;
+} rt_sphere;
+
+/* `Triangle a b c n mat` (src/Types.hs:78-82); n is the STORED normal (it is not
+ * recomputed: src/RayTracer.hs:77, and scenes hand-write it, BenchmarkScene.hs:50-58). */
+typedef struct rt_triangle {
+  float a[3], b[3], c[3], n[3];
+  int32_t material;
+  int32_t object_id;
+} rt_triangle;
+
+/* `Material` (src/Types.hs:27-37).  log_atten is what makeMaterial stores:
+ * log of the attenuation colour (src/Surfaces.hs:22-24). */
+typedef struct rt_material {
+  float diffuse[3];
+  float specular[3];
+  float phong;
+  float refl;
+  float refr_ix;
+  float log_atten[3];
+} rt_material;
+
+/* `Light corner edgeA edgeB color` (src/Types.hs:102-106). */
+typedef struct rt_light {
+  float corner[3], edge_a[3], edge_b[3], color[3];
+} rt_light;
+
+typedef struct rt_scene {
+  const rt_bvh_node *nodes;     int32_t n_nodes;
+  const uint32_t *leaf_refs;    int32_t n_refs;
+  const rt_sphere *spheres;     int32_t n_spheres;
+  const rt_triangle *triangles; int32_t n_triangles;
+  const rt_material *materials; int32_t n_materials;
+  const rt_light *lights;       int32_t n_lights;
+} rt_scene;
+
+/* The scalar fields of `World` (src/Types.hs:132-146) as configToWorld fills
+ * them (src/Main.hs:104-120): aa = wAntiAliasing = floor(sqrt(rays per pixel)),
+ * (u,v,w) = getCam eye lookAt up (src/Main.hs:122-126). */
+typedef struct rt_camera {
+  int32_t img_w, img_h;          /* wImgWd, wImgHt (whole numbers)          */
+  float view_w, view_h, view_d;  /* wViewWd, wViewHt, wViewDt               */
+  int32_t aa;                    /* wAntiAliasing; samples per pixel = aa*aa */
+  float lens;                    /* wLens                                    */
+  float up[3], eye[3];           /* wUp (unused by the path), wEye           */
+  float u[3], v[3], w[3];        /* wCamera                                  */
+  float ambient[3];              /* wAmbient                                 */
+  int32_t max_depth;             /* wMaxDepth                                */
+} rt_camera;
+
+/* ---- render flags ----------------------------------------------------- */
+
+/* Arithmetic mode.  STRICT (default, 0): every fp32 add/sub/mul/div/sqrt is a
+ * separate IEEE operation in the reference's order (GHC's x86-64 code generator
+ * emits no FMA) -> hit decisions are bit-identical to the CPU oracle.
+ * FMA: same kernels compiled with -ffp-contract=fast (Geometry3 math contracted
+ * to v_fma_f32); hit decisions on ill-conditioned self-intersections may differ,
+ * the mismatch rate is reported by the parity tests. */
+#define RT_FLAG_FMA            0x1u
+/* Trace reflection rays whose weight is exactly (0,0,0) too, as the reference
+ * does (src/RayTracer.hs:129-131 always recurses).  Off by default: such a
+ * subtree can only change the result if it produces inf/NaN. */
+#define RT_FLAG_TRACE_ZERO_WEIGHT 0x2u
+/* Visit every node whose ancestors pass hitsBox, like hitBVH
+ * (src/RayTracer.hs:404-412): no front-to-back order, no t-range pruning. */
+#define RT_FLAG_NO_PRUNE       0x4u
+/* Count box / sphere / triangle tests (slower kernels; for roofline numbers). */
+#define RT_FLAG_COUNT_TESTS    0x8u
+
+#define RT_HIT_NONE 0xffffffffu
+
+typedef struct rt_stats {
+  uint64_t rays_primary;      /* rays actually traversed, by kind          */
+  uint64_t rays_shadow;
+  uint64_t rays_reflection;
+  uint64_t rays_refraction;
+  uint64_t box_tests;         /* only with RT_FLAG_COUNT_TESTS             */
+  uint64_t sphere_tests;
+  uint64_t triangle_tests;
+  uint64_t primary_hits;
+  uint64_t reserved[4];
+  double ms_kernel;           /* trace/shade kernel, HIP events on its stream */
+  double ms_total;            /* whole call incl. copies                      */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ---- entry points ----------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  No counterpart in the reference
+ * (which has no device); it stands where Main.run builds the World
+ * (src/Main.hs:41-44). */
+int rt_init(int device, rt_ctx **out);
+void rt_shutdown(rt_ctx *ctx);
+
+/* Upload wObjects (the BVH with its objects and their materials) and wLights:
+ * replaces the in-memory `World` fields of src/Types.hs:142-144. */
+int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
+
+/* The remaining World fields (src/Types.hs:132-141,143,145). */
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+
+/* The output of generateGrids (src/RayTracer.hs:462-467) before `cycle`:
+ * n_grids (= img_w + 10, src/RayTracer.hs:20) grids of spp (= aa*aa) samples of
+ * `F6 p q r0 r1 s0 s1` (src/Types.hs:108-114); f6 is [n_grids][spp][6] floats.
+ * Pixel k in render's list order uses grid k mod n_grids. */
+int rt_set_samples(rt_ctx *ctx, const float *f6, int32_t n_grids, int32_t spp);
+
+/* Static tile partition for data-parallel rendering: this context renders the
+ * tiles t with t % nranks == rank.  (0,1) = whole frame (default). */
+int rt_set_partition(rt_ctx *ctx, int32_t rank, int32_t nranks);
+
+/* Geometry of the tile decomposition for the current camera/samples. */
+typedef struct rt_tiling {
+  int32_t tile_w, tile_h;      /* pixels                                  */
+  int32_t tiles_x, tiles_y;    /* tiles across / down the image           */
+  int32_t n_tiles;             /* tiles_x * tiles_y                       */
+  int32_t n_local_tiles;       /* tiles of this rank                      */
+} rt_tiling;
+int rt_get_tiling(rt_ctx *ctx, rt_tiling *out);
+
+/* render (src/RayTracer.hs:18-23).  rgb_out: img_w*img_h*3 floats, pixel order
+ * of render's list (top row first, j = H-1..0, i = 0..W-1).  With a partition,
+ * pixels of other ranks' tiles are set to 0.  primary_hit_ids (may be
+ * NULL): img_w*img_h*spp object ids of the first-generation hit (RT_HIT_NONE =
+ * miss), sample-major within the pixel.  stats may be NULL.  Host pointers. */
+int rt_render(rt_ctx *ctx, uint32_t flags, float *rgb_out, uint32_t *primary_hit_ids,
+              rt_stats *stats);
+
+/* Same, device pointers, enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * context's own stream) without a host sync; inputs stay resident in HBM.
+ * d_rgb as rgb_out above.  With nranks > 1 use rt_render_tiles_async instead. */
+int rt_render_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_primary_hit_ids,
+                    void *hip_stream);
+
+/* Partitioned form: writes this rank's tiles compactly,
+ * d_tiles[n_local_tiles][tile_h][tile_w][3] floats (local tile l is global tile
+ * rank + l*nranks); the buffers of all ranks are gathered (RCCL) and passed to
+ * rt_assemble_async on the root. */
+int rt_render_tiles_async(rt_ctx *ctx, uint32_t flags, float *d_tiles, void *hip_stream);
+
+/* Root side of the gather: d_gathered holds the nranks compact tile buffers
+ * back to back, each padded to `stride_floats` floats; scatters them into
+ * d_rgb (img_w*img_h*3 floats, render's order). */
+int rt_assemble_async(rt_ctx *ctx, const float *d_gathered, int32_t nranks,
+                      size_t stride_floats, float *d_rgb, void *hip_stream);
+
+/* Wait for the stream of the last render call and fill stats (ray counters and
+ * ms_kernel of that call). */
+int rt_collect(rt_ctx *ctx, void *hip_stream, rt_stats *stats);
+
+/* The 8-bit quantisation of writePPM (src/Main.hs:99-101,128-138):
+ * out = truncate(255 * clamp x).  n = number of floats.  Device pointers. */
+int rt_quantize_async(rt_ctx *ctx, const float *d_rgb, uint8_t *d_rgb8, size_t n,
+                      void *hip_stream);
+
+const char *rt_last_error(rt_ctx *ctx);
+int rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

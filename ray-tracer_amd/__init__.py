@@ -1,0 +1,495 @@
+"""ray-tracer_amd -- MI355X-native trace/shade path of jrraymond/ray-tracer.
+
+Host-side mirror (Python, ctypes) of the reference interface around ``render``:
+
+    reference (Haskell)                         here
+    -----------------------------------------   ---------------------------------
+    Config / benchNConfig   (Main.hs:50-62)     Config, default_config(name)
+    configToWorld, getCam   (Main.hs:104-126)   config_to_world(config, scene)
+    sahBVH / noBVH          (BVH.hs:34,130)     Scene.build_bvh("sah" | "none")
+    generateGrids           (RayTracer.hs:462)  generate_grids(seed, num, aa)
+    render rng world        (RayTracer.hs:18)   render(grids, world, ...)
+    writePPM                (Main.hs:128-138)   write_ppm(path, w, h, pixels)
+
+The product path is librt_mi355x.so (hand-written HIP, C ABI in
+include/rt_mi355x.h).  There is NO CPU fallback: ``render`` raises if the HIP
+library is missing or no GPU is present.  The package name contains a hyphen, so
+import it with ``importlib.import_module("ray-tracer_amd")`` (see rt_amd.py at the
+repository root for a one-line shim).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "librt_host.so")
+DEVICE_LIB_PATH = os.path.join(LIB_DIR, "librt_mi355x.so")
+
+# --------------------------------------------------------------------------
+# PODs of include/rt_mi355x.h / include/rt_host.h
+# --------------------------------------------------------------------------
+f32, i32, u32, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("xmin", f32), ("xmax", f32), ("ymin", f32), ("ymax", f32), ("zmin", f32),
+                ("zmax", f32), ("left", i32), ("right", i32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", f32 * 3), ("radius", f32), ("material", i32), ("object_id", i32)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("a", f32 * 3), ("b", f32 * 3), ("c", f32 * 3), ("n", f32 * 3), ("material", i32),
+                ("object_id", i32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", f32 * 3), ("specular", f32 * 3), ("phong", f32), ("refl", f32),
+                ("refr_ix", f32), ("log_atten", f32 * 3)]
+
+
+class Light(C.Structure):
+    _fields_ = [("corner", f32 * 3), ("edge_a", f32 * 3), ("edge_b", f32 * 3), ("color", f32 * 3)]
+
+
+class SceneView(C.Structure):
+    _fields_ = [("nodes", C.POINTER(BvhNode)), ("n_nodes", i32),
+                ("leaf_refs", C.POINTER(u32)), ("n_refs", i32),
+                ("spheres", C.POINTER(Sphere)), ("n_spheres", i32),
+                ("triangles", C.POINTER(Triangle)), ("n_triangles", i32),
+                ("materials", C.POINTER(Material)), ("n_materials", i32),
+                ("lights", C.POINTER(Light)), ("n_lights", i32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("img_w", i32), ("img_h", i32), ("view_w", f32), ("view_h", f32), ("view_d", f32),
+                ("aa", i32), ("lens", f32), ("up", f32 * 3), ("eye", f32 * 3), ("u", f32 * 3),
+                ("v", f32 * 3), ("w", f32 * 3), ("ambient", f32 * 3), ("max_depth", i32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", u64), ("rays_shadow", u64), ("rays_reflection", u64),
+                ("rays_refraction", u64), ("box_tests", u64), ("sphere_tests", u64),
+                ("triangle_tests", u64), ("primary_hits", u64), ("reserved", u64 * 4),
+                ("ms_kernel", C.c_double), ("ms_total", C.c_double)]
+
+    @property
+    def rays_total(self) -> int:
+        return (self.rays_primary + self.rays_shadow + self.rays_reflection + self.rays_refraction)
+
+    def as_dict(self) -> dict:
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["rays_total"] = self.rays_total
+        return d
+
+
+class Tiling(C.Structure):
+    _fields_ = [("tile_w", i32), ("tile_h", i32), ("tiles_x", i32), ("tiles_y", i32),
+                ("n_tiles", i32), ("n_local_tiles", i32)]
+
+
+class HostConfig(C.Structure):
+    _fields_ = [("image_w", i32), ("image_h", i32), ("view_w", i32), ("view_h", i32),
+                ("view_d", i32), ("reflection_depth", i32), ("anti_aliasing", i32), ("lens", f32),
+                ("up", f32 * 3), ("eye", f32 * 3), ("look_at", f32 * 3)]
+
+
+REF_TRIANGLE = 0x80000000
+HIT_NONE = 0xFFFFFFFF
+FLAG_FMA = 0x1
+FLAG_TRACE_ZERO_WEIGHT = 0x2
+FLAG_NO_PRUNE = 0x4
+FLAG_COUNT_TESTS = 0x8
+
+DEVICE_SYMBOLS = [
+    "rt_init", "rt_shutdown", "rt_upload_scene", "rt_set_camera", "rt_set_samples",
+    "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
+    "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
+]
+HOST_SYMBOLS = [
+    "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_build_bvh",
+    "rth_scene_view", "rth_scene_n_objects", "rth_scene_bvh_depth", "rth_default_config",
+    "rth_config_to_camera", "rth_generate_grids", "rth_write_ppm", "rth_quantize",
+    "rth_material_by_name", "rth_make_triangle",
+]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+# --------------------------------------------------------------------------
+# library loading
+# --------------------------------------------------------------------------
+_host = None
+_dev = None
+
+
+def host_lib() -> C.CDLL:
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RtError(f"{HOST_LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` in the repository root")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.rth_scene_builtin.restype = C.c_void_p
+        L.rth_scene_builtin.argtypes = [C.c_char_p]
+        L.rth_scene_create.restype = C.c_void_p
+        L.rth_scene_create.argtypes = [C.POINTER(Sphere), i32, C.POINTER(Triangle), i32,
+                                       C.POINTER(u32), i32, C.POINTER(Material), i32,
+                                       C.POINTER(Light), i32]
+        L.rth_scene_free.argtypes = [C.c_void_p]
+        L.rth_scene_free.restype = None
+        L.rth_scene_build_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.rth_scene_view.argtypes = [C.c_void_p, C.POINTER(SceneView)]
+        L.rth_scene_n_objects.argtypes = [C.c_void_p]
+        L.rth_scene_bvh_depth.argtypes = [C.c_void_p]
+        L.rth_default_config.argtypes = [C.c_char_p, C.POINTER(HostConfig)]
+        L.rth_config_to_camera.argtypes = [C.POINTER(HostConfig), C.POINTER(Camera)]
+        L.rth_generate_grids.argtypes = [u64, i32, i32, C.POINTER(f32)]
+        L.rth_write_ppm.argtypes = [C.c_char_p, i32, i32, C.POINTER(f32)]
+        L.rth_quantize.argtypes = [C.POINTER(f32), C.c_size_t, C.POINTER(C.c_uint8)]
+        L.rth_quantize.restype = None
+        L.rth_material_by_name.argtypes = [C.c_char_p, C.POINTER(Material)]
+        L.rth_make_triangle.argtypes = [f32 * 3, f32 * 3, f32 * 3, i32, C.POINTER(Triangle)]
+        L.rth_make_triangle.restype = None
+        _host = L
+    return _host
+
+
+def device_lib() -> C.CDLL:
+    """The HIP library.  Fails loudly when it has not been built (no fallback)."""
+    global _dev
+    if _dev is None:
+        if not os.path.exists(DEVICE_LIB_PATH):
+            raise RtError(f"{DEVICE_LIB_PATH} missing: the HIP extension is not built; there is "
+                          "no CPU fallback for the trace/shade path")
+        L = C.CDLL(DEVICE_LIB_PATH)
+        vp = C.c_void_p
+        L.rt_init.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rt_shutdown.argtypes = [vp]
+        L.rt_shutdown.restype = None
+        L.rt_upload_scene.argtypes = [vp, C.POINTER(SceneView)]
+        L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.rt_set_samples.argtypes = [vp, C.POINTER(f32), i32, i32]
+        L.rt_set_partition.argtypes = [vp, i32, i32]
+        L.rt_get_tiling.argtypes = [vp, C.POINTER(Tiling)]
+        L.rt_render.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(u32), C.POINTER(Stats)]
+        L.rt_render_async.argtypes = [vp, u32, vp, vp, vp]
+        L.rt_render_tiles_async.argtypes = [vp, u32, vp, vp]
+        L.rt_assemble_async.argtypes = [vp, vp, i32, C.c_size_t, vp, vp]
+        L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
+        L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.rt_last_error.argtypes = [vp]
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_abi_version.restype = C.c_int
+        _dev = L
+    return _dev
+
+
+# --------------------------------------------------------------------------
+# host-side mirror of the reference API
+# --------------------------------------------------------------------------
+Vec3 = Tuple[float, float, float]
+
+
+@dataclass
+class Config:
+    """``Config`` of src/Main.hs:50-62 (cScene is the `scene` passed separately)."""
+    image_width: int = 400
+    image_height: int = 300
+    view_width: int = 4
+    view_height: int = 3
+    view_distance: int = 7
+    reflection_depth: int = 3
+    anti_aliasing: int = 1          # rays per pixel
+    lens: float = 0.0
+    up: Vec3 = (0.0, 1.0, 0.0)
+    eye: Vec3 = (0.0, 0.0, 0.0)
+    look_at: Vec3 = (1.0, 0.0, 0.0)
+
+    def _c(self) -> HostConfig:
+        return HostConfig(self.image_width, self.image_height, self.view_width, self.view_height,
+                          self.view_distance, self.reflection_depth, self.anti_aliasing, self.lens,
+                          (f32 * 3)(*self.up), (f32 * 3)(*self.eye), (f32 * 3)(*self.look_at))
+
+
+def default_config(name: str) -> Config:
+    """benchNConfig of src/Main.hs:151-235 ("bench1" .. "bench6", "scene1")."""
+    hc = HostConfig()
+    if host_lib().rth_default_config(name.encode(), C.byref(hc)) != 0:
+        raise RtError(f"unknown config {name!r}")
+    return Config(hc.image_w, hc.image_h, hc.view_w, hc.view_h, hc.view_d, hc.reflection_depth,
+                  hc.anti_aliasing, hc.lens, tuple(hc.up), tuple(hc.eye), tuple(hc.look_at))
+
+
+class Scene:
+    """[Object] + [Light] (+ the BVH built from them): wObjects / wLights."""
+
+    def __init__(self, handle: int):
+        if not handle:
+            raise RtError("scene construction failed")
+        self._h = C.c_void_p(handle)
+        self._view: Optional[SceneView] = None
+
+    @classmethod
+    def builtin(cls, name: str, bvh: str = "sah") -> "Scene":
+        s = cls(host_lib().rth_scene_builtin(name.encode()))
+        s.build_bvh(bvh)
+        return s
+
+    @classmethod
+    def create(cls, spheres: Sequence[Sphere], triangles: Sequence[Triangle],
+               order: Sequence[int], materials: Sequence[Material], lights: Sequence[Light],
+               bvh: str = "sah") -> "Scene":
+        sa = (Sphere * max(1, len(spheres)))(*spheres)
+        ta = (Triangle * max(1, len(triangles)))(*triangles)
+        oa = (u32 * max(1, len(order)))(*order)
+        ma = (Material * max(1, len(materials)))(*materials)
+        la = (Light * max(1, len(lights)))(*lights)
+        s = cls(host_lib().rth_scene_create(sa, len(spheres), ta, len(triangles), oa, len(order),
+                                            ma, len(materials), la, len(lights)))
+        s.build_bvh(bvh)
+        return s
+
+    def build_bvh(self, builder: str = "sah") -> None:
+        """sahBVH (BoundingVolumeHierarchy.hs:34-51) or noBVH (:130-131)."""
+        code = {"sah": 0, "none": 1}[builder]
+        if host_lib().rth_scene_build_bvh(self._h, code) != 0:
+            raise RtError("BVH build failed")
+        self._view = None
+
+    @property
+    def view(self) -> SceneView:
+        if self._view is None:
+            v = SceneView()
+            host_lib().rth_scene_view(self._h, C.byref(v))
+            self._view = v
+        return self._view
+
+    @property
+    def n_objects(self) -> int:
+        return host_lib().rth_scene_n_objects(self._h)
+
+    @property
+    def bvh_depth(self) -> int:
+        return host_lib().rth_scene_bvh_depth(self._h)
+
+    def nodes(self) -> np.ndarray:
+        v = self.view
+        dt = np.dtype([("box", "<f4", (6,)), ("left", "<i4"), ("right", "<i4")])
+        if v.n_nodes == 0:
+            return np.zeros(0, dt)
+        return np.ctypeslib.as_array(C.cast(v.nodes, C.POINTER(C.c_uint8)),
+                                     (v.n_nodes * 32,)).view(dt).copy()
+
+    def leaf_refs(self) -> np.ndarray:
+        v = self.view
+        if v.n_refs == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(v.leaf_refs, (v.n_refs,)).copy()
+
+    def __del__(self):
+        try:
+            if self._h:
+                host_lib().rth_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+@dataclass
+class World:
+    """``World`` of src/Types.hs:132-146: camera scalars + scene."""
+    camera: Camera
+    scene: Scene
+
+    @property
+    def width(self) -> int:
+        return self.camera.img_w
+
+    @property
+    def height(self) -> int:
+        return self.camera.img_h
+
+    @property
+    def spp(self) -> int:
+        return self.camera.aa * self.camera.aa
+
+
+def config_to_world(config: Config, scene: Scene) -> World:
+    """configToWorld (src/Main.hs:104-120); the scene already carries objects+lights."""
+    cam = Camera()
+    hc = config._c()
+    if host_lib().rth_config_to_camera(C.byref(hc), C.byref(cam)) != 0:
+        raise RtError("config_to_world failed")
+    return World(cam, scene)
+
+
+def generate_grids(seed: int, num: int, aa: int) -> np.ndarray:
+    """generateGrids (src/RayTracer.hs:462-467) before `cycle`: [num][aa*aa][6] float32."""
+    out = np.empty((num, aa * aa, 6), np.float32)
+    rc = host_lib().rth_generate_grids(seed, num, aa, out.ctypes.data_as(C.POINTER(f32)))
+    if rc != 0:
+        raise RtError("generate_grids failed")
+    return out
+
+
+def quantize(rgb: np.ndarray) -> np.ndarray:
+    """toTxt of writePPM (src/Main.hs:131): truncate(255 * clamp x) as uint8."""
+    a = np.ascontiguousarray(rgb, np.float32)
+    out = np.empty(a.shape, np.uint8)
+    host_lib().rth_quantize(a.ctypes.data_as(C.POINTER(f32)), a.size,
+                            out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def write_ppm(path: str, w: int, h: int, pixels: np.ndarray) -> None:
+    """writePPM (src/Main.hs:128-138): ASCII P3, one line of values."""
+    a = np.ascontiguousarray(pixels, np.float32)
+    assert a.size == w * h * 3
+    if host_lib().rth_write_ppm(path.encode(), w, h, a.ctypes.data_as(C.POINTER(f32))) != 0:
+        raise RtError(f"cannot write {path}")
+
+
+def material(name: str) -> Material:
+    m = Material()
+    if host_lib().rth_material_by_name(name.encode(), C.byref(m)) != 0:
+        raise RtError(f"unknown material {name!r}")
+    return m
+
+
+def make_triangle(a: Vec3, b: Vec3, c: Vec3, material_index: int) -> Triangle:
+    t = Triangle()
+    host_lib().rth_make_triangle((f32 * 3)(*a), (f32 * 3)(*b), (f32 * 3)(*c), material_index,
+                                 C.byref(t))
+    return t
+
+
+# --------------------------------------------------------------------------
+# the device path
+# --------------------------------------------------------------------------
+class Renderer:
+    """One rt_ctx (one GPU).  Thin, explicit wrapper over the C ABI."""
+
+    def __init__(self, device: int = 0):
+        self.lib = device_lib()
+        h = C.c_void_p()
+        rc = self.lib.rt_init(device, C.byref(h))
+        if rc != 0 or not h:
+            raise RtError(f"rt_init(device={device}) failed with {rc}: is a GPU present?")
+        self._h = h
+        self.world: Optional[World] = None
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            msg = self.lib.rt_last_error(self._h)
+            raise RtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_world(self, world: World) -> None:
+        self._check(self.lib.rt_upload_scene(self._h, C.byref(world.scene.view)), "rt_upload_scene")
+        self._check(self.lib.rt_set_camera(self._h, C.byref(world.camera)), "rt_set_camera")
+        self.world = world
+
+    def set_samples(self, grids: np.ndarray) -> None:
+        g = np.ascontiguousarray(grids, np.float32)
+        assert g.ndim == 3 and g.shape[2] == 6
+        self._check(self.lib.rt_set_samples(self._h, g.ctypes.data_as(C.POINTER(f32)), g.shape[0],
+                                            g.shape[1]), "rt_set_samples")
+
+    def set_partition(self, rank: int, nranks: int) -> None:
+        self._check(self.lib.rt_set_partition(self._h, rank, nranks), "rt_set_partition")
+
+    def tiling(self) -> Tiling:
+        t = Tiling()
+        self._check(self.lib.rt_get_tiling(self._h, C.byref(t)), "rt_get_tiling")
+        return t
+
+    def render(self, flags: int = 0, want_hit_ids: bool = False):
+        """rt_render with host buffers.  Returns (rgb[H*W,3], hit_ids or None, Stats)."""
+        w = self.world
+        assert w is not None
+        rgb = np.zeros((w.height * w.width, 3), np.float32)
+        ids = np.zeros((w.height * w.width, w.spp), np.uint32) if want_hit_ids else None
+        st = Stats()
+        self._check(self.lib.rt_render(self._h, flags, rgb.ctypes.data_as(C.POINTER(f32)),
+                                       ids.ctypes.data_as(C.POINTER(u32)) if want_hit_ids else None,
+                                       C.byref(st)), "rt_render")
+        return rgb, ids, st
+
+    # device-pointer forms (pointers are plain integers, e.g. torch.Tensor.data_ptr())
+    def render_async(self, d_rgb: int, d_hit_ids: int = 0, flags: int = 0, stream: int = 0) -> None:
+        self._check(self.lib.rt_render_async(self._h, flags, d_rgb, d_hit_ids or None,
+                                             stream or None), "rt_render_async")
+
+    def render_tiles_async(self, d_tiles: int, flags: int = 0, stream: int = 0) -> None:
+        self._check(self.lib.rt_render_tiles_async(self._h, flags, d_tiles, stream or None),
+                    "rt_render_tiles_async")
+
+    def assemble_async(self, d_gathered: int, nranks: int, stride_floats: int, d_rgb: int,
+                       stream: int = 0) -> None:
+        self._check(self.lib.rt_assemble_async(self._h, d_gathered, nranks, stride_floats, d_rgb,
+                                               stream or None), "rt_assemble_async")
+
+    def quantize_async(self, d_rgb: int, d_rgb8: int, n: int, stream: int = 0) -> None:
+        self._check(self.lib.rt_quantize_async(self._h, d_rgb, d_rgb8, n, stream or None),
+                    "rt_quantize_async")
+
+    def collect(self, stream: int = 0) -> Stats:
+        st = Stats()
+        self._check(self.lib.rt_collect(self._h, stream or None, C.byref(st)), "rt_collect")
+        return st
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.rt_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render(grids: np.ndarray, world: World, flags: int = 0, device: int = 0) -> np.ndarray:
+    """``render rng world`` (src/RayTracer.hs:18-23) with the grids given explicitly.
+
+    Returns the [Color] list as float32 [H*W, 3], top row first.  Runs on the GPU
+    through librt_mi355x.so; raises RtError when that is impossible.
+    """
+    r = Renderer(device)
+    try:
+        r.set_world(world)
+        r.set_samples(grids)
+        rgb, _, _ = r.render(flags)
+        return rgb
+    finally:
+        r.close()
+
+
+def tile_shape(spp: int) -> Tuple[int, int]:
+    """Tile decomposition used by the device library (pure index math, mirrored here
+    for the CPU-side multi-rank tests): about 1024 samples per tile, power-of-two
+    sides, width >= height."""
+    px = max(1, 1024 // max(1, spp))
+    lg = max(0, px.bit_length() - 1)
+    tw = 1 << ((lg + 1) // 2)
+    th = 1 << (lg // 2)
+    return tw, th
+
+
+def tiles_of_rank(width: int, height: int, spp: int, rank: int, nranks: int):
+    """Global tile ids of `rank` under the static interleaved partition (t % nranks)."""
+    tw, th = tile_shape(spp)
+    tx = (width + tw - 1) // tw
+    ty = (height + th - 1) // th
+    return [t for t in range(tx * ty) if t % nranks == rank], (tw, th, tx, ty)

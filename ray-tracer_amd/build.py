@@ -1,0 +1,77 @@
+"""Build recipes for the native libraries (called by __graft_entry__.build()).
+
+    librt_host.so    g++     host-side scene / BVH / sample-table producer
+    librt_mi355x.so  hipcc   the C-ABI device library (gfx950); kernels compiled twice,
+                             -ffp-contract=off (strict) and -ffp-contract=fast (fma)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+INC = os.path.join(ROOT, "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build_host(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "librt_host.so")
+    srcs = [os.path.join(CSRC, "host", "rt_host.cpp"), os.path.join(INC, "rt_host.h"),
+            os.path.join(INC, "rt_mi355x.h")]
+    if force or _stale(out, srcs):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+              "-I" + INC, srcs[0], "-o", out])
+    return out
+
+
+def build_device(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    obj = os.path.join(HERE, "build")
+    os.makedirs(obj, exist_ok=True)
+    out = os.path.join(LIB, "librt_mi355x.so")
+    common = [os.path.join(CSRC, "rt_device.h"), os.path.join(INC, "rt_mi355x.h")]
+    kern = os.path.join(CSRC, "rt_kernels.inl")
+    units = [
+        ("rt_kernels_strict", ["-ffp-contract=off"], [kern]),
+        ("rt_kernels_fma", ["-ffp-contract=fast"], [kern]),
+        ("rt_api", ["-ffp-contract=off"], []),
+    ]
+    base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
+    objs = []
+    relink = force
+    for name, flags, extra in units:
+        src = os.path.join(CSRC, name + ".hip")
+        o = os.path.join(obj, name + ".o")
+        if force or _stale(o, [src] + common + extra):
+            _run(base + flags + ["-c", src, "-o", o])
+            relink = True
+        objs.append(o)
+    if relink or _stale(out, objs):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
+def build_all(force=False):
+    return build_host(force), build_device(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

@@ -1,0 +1,572 @@
+// rt_api.hip -- host side of librt_mi355x.so: the C ABI of include/rt_mi355x.h.
+// Context, scene validation + repacking into the device layout (rt_device.h), launch
+// of the persistent trace/shade kernel, tile assembly and 8-bit quantisation kernels.
+// No torch, no CPU fallback: every entry point needs a HIP device.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+using namespace rtdev;
+
+struct rt_ctx {
+  int device = 0;
+  int n_cus = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::string err;
+
+  // scene
+  float4 *d_nodes = nullptr, *d_prims = nullptr;
+  float *d_materials = nullptr, *d_lights = nullptr;
+  int n_lights = 0, has_root = 0, tree_depth = 0;
+  bool have_scene = false;
+  // camera / samples
+  rt_camera cam{};
+  bool have_cam = false;
+  float *d_f6 = nullptr;
+  int n_grids = 0, spp = 0;
+  bool have_samples = false;
+  // partition / tiling
+  int rank = 0, nranks = 1;
+  rt_tiling tiling{};
+  // work memory
+  float *d_scratch = nullptr;
+  size_t scratch_floats = 0;
+  unsigned long long scratch_stride = 0;
+  int scratch_waves = 0;
+  unsigned *d_tile_counter = nullptr;
+  unsigned long long *d_stats = nullptr;
+  // staging for the host-pointer form
+  float *d_rgb = nullptr;
+  size_t d_rgb_floats = 0;
+  uint32_t *d_ids = nullptr;
+  size_t d_ids_count = 0;
+  bool prepared = false;
+  int stack_depth = 8;
+};
+
+namespace {
+
+int fail(rt_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail((c), RT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+template <class T>
+int upload(rt_ctx *c, T **dst, const void *src, size_t bytes) {
+  if (*dst) {
+    (void)hipFree(*dst);
+    *dst = nullptr;
+  }
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(c, hipMalloc((void **)dst, bytes));
+  if (src) HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+void compute_tiling(rt_ctx *c) {
+  // ~1024 samples per tile, power-of-two sides, width >= height (mirrored by
+  // tile_shape() in ray-tracer_amd/__init__.py for the CPU-side partition tests)
+  int spp = std::max(1, c->spp);
+  int px = std::max(1, 1024 / spp);
+  int lg = 0;
+  while ((2 << lg) <= px) ++lg;
+  rt_tiling &t = c->tiling;
+  t.tile_w = 1 << ((lg + 1) / 2);
+  t.tile_h = 1 << (lg / 2);
+  t.tiles_x = (c->cam.img_w + t.tile_w - 1) / t.tile_w;
+  t.tiles_y = (c->cam.img_h + t.tile_h - 1) / t.tile_h;
+  t.n_tiles = t.tiles_x * t.tiles_y;
+  t.n_local_tiles = (t.n_tiles > c->rank) ? (t.n_tiles - c->rank + c->nranks - 1) / c->nranks : 0;
+}
+
+struct Repack {
+  const rt_scene *sc;
+  std::vector<float> nodes;  // 16 floats per device node
+  std::vector<float> prims;  // 16 floats per record
+  std::vector<char> seen;
+  int max_depth = 0;
+  std::string err;
+
+  static void put_i(float *p, int v) { std::memcpy(p, &v, 4); }
+
+  // emits the records of a leaf (reversed list order), returns the leaf ref
+  int emit_leaf(const rt_bvh_node &n) {
+    int first_ref = -1 - n.left, count = n.right;
+    int first_rec = (int)(prims.size() / 16);
+    for (int k = count - 1; k >= 0; --k) {
+      uint32_t r = sc->leaf_refs[first_ref + k];
+      float rec[16] = {0};
+      if (r & RT_REF_TRIANGLE) {
+        const rt_triangle &t = sc->triangles[RT_REF_INDEX(r)];
+        for (int a = 0; a < 3; ++a) {
+          rec[0 + a] = t.a[a];
+          rec[3 + a] = t.a[a] - t.b[a];  // (a,b,c) = A - B   RayTracer.hs:362
+          rec[6 + a] = t.a[a] - t.c[a];  // (d,e,f) = A - C   RayTracer.hs:363
+          rec[9 + a] = t.n[a];
+        }
+        put_i(rec + 12, 1);
+        put_i(rec + 13, t.material);
+        put_i(rec + 14, t.object_id);
+      } else {
+        const rt_sphere &s = sc->spheres[r];
+        rec[0] = s.center[0];
+        rec[1] = s.center[1];
+        rec[2] = s.center[2];
+        rec[3] = s.radius;
+        rec[4] = s.radius * s.radius;  // radius*radius   RayTracer.hs:344
+        put_i(rec + 12, 0);
+        put_i(rec + 13, s.material);
+        put_i(rec + 14, s.object_id);
+      }
+      put_i(rec + 15, 0);
+      prims.insert(prims.end(), rec, rec + 16);
+    }
+    put_i(&prims[(size_t)first_rec * 16 + 15], count);
+    return -1 - first_rec;
+  }
+
+  // returns the device ref of host node `idx` (inner -> device node index, leaf -> leaf ref)
+  int visit(int idx, int depth) {
+    if (!err.empty()) return REF_NONE;
+    if (idx < 0 || idx >= sc->n_nodes) { err = "child index out of range"; return REF_NONE; }
+    if (seen[idx]) { err = "node reachable twice (not a tree)"; return REF_NONE; }
+    seen[idx] = 1;
+    if (depth > max_depth) max_depth = depth;
+    if (depth > 4096) { err = "tree too deep"; return REF_NONE; }
+    const rt_bvh_node &n = sc->nodes[idx];
+    if (n.left < 0) {
+      long first = -1L - (long)n.left;
+      if (n.right < 1 || first + n.right > sc->n_refs) { err = "leaf range out of bounds"; return REF_NONE; }
+      for (int k = 0; k < n.right; ++k) {
+        uint32_t r = sc->leaf_refs[first + k];
+        uint32_t ix = RT_REF_INDEX(r);
+        int mat;
+        if (r & RT_REF_TRIANGLE) {
+          if ((int)ix >= sc->n_triangles) { err = "triangle ref out of range"; return REF_NONE; }
+          mat = sc->triangles[ix].material;
+        } else {
+          if ((int)ix >= sc->n_spheres) { err = "sphere ref out of range"; return REF_NONE; }
+          mat = sc->spheres[ix].material;
+        }
+        if (mat < 0 || mat >= sc->n_materials) { err = "material index out of range"; return REF_NONE; }
+      }
+      return emit_leaf(n);
+    }
+    if (n.right < 0) { err = "inner node with negative right child"; return REF_NONE; }
+    int me = (int)(nodes.size() / 16);
+    nodes.resize(nodes.size() + 16, 0.0f);
+    int l = visit(n.left, depth + 1);
+    int r = visit(n.right, depth + 1);
+    if (!err.empty()) return REF_NONE;
+    float *d = &nodes[(size_t)me * 16];
+    std::memcpy(d + 0, &sc->nodes[n.left].xmin, 24);
+    std::memcpy(d + 6, &sc->nodes[n.right].xmin, 24);
+    put_i(d + 12, l);
+    put_i(d + 13, r);
+    return me;
+  }
+};
+
+__global__ void assemble_kernel(const float *__restrict__ gathered, int nranks, size_t stride,
+                                float *__restrict__ rgb, int W, int H, int tile_w, int tile_h,
+                                int tiles_x, int n_tiles) {
+  const int tile_px = tile_w * tile_h;
+  size_t total = (size_t)n_tiles * tile_px;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int gt = (int)(i / tile_px), pit = (int)(i % tile_px);
+    int px = (gt % tiles_x) * tile_w + pit % tile_w;
+    int py = (gt / tiles_x) * tile_h + pit / tile_w;
+    if (px >= W || py >= H) continue;
+    int rank = gt % nranks, l = gt / nranks;
+    const float *s = gathered + (size_t)rank * stride + ((size_t)l * tile_px + pit) * 3;
+    float *d = rgb + ((size_t)py * W + px) * 3;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+  }
+}
+
+// clamp (Main.hs:99-101) then truncate (255*) (Main.hs:131).  NaN -> 0 (the
+// reference's `truncate NaN` is undefined garbage).
+__global__ void quantize_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float x = in[i];
+    float c = (x < 0) ? 0.0f : ((x > 1) ? 1.0f : x);
+    float y = 255 * c;
+    out[i] = (y == y) ? (uint8_t)(int)y : (uint8_t)0;
+  }
+}
+
+int prepare(rt_ctx *c, uint32_t flags) {
+  if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_upload_scene has not been called");
+  if (!c->have_cam) return fail(c, RT_ERR_STATE, "rt_set_camera has not been called");
+  if (!c->have_samples) return fail(c, RT_ERR_STATE, "rt_set_samples has not been called");
+  if (c->spp != c->cam.aa * c->cam.aa)
+    return fail(c, RT_ERR_INVALID, "samples have spp=%d but camera aa=%d needs %d", c->spp, c->cam.aa,
+                c->cam.aa * c->cam.aa);
+  (void)flags;
+  if (c->prepared) return RT_OK;
+  compute_tiling(c);
+  c->stack_depth = std::max(4, (c->tree_depth + 3) & ~3);
+  int tile_samples = c->tiling.tile_w * c->tiling.tile_h * c->spp;
+  c->scratch_stride = (scratch_floats_per_wave(c->cam.max_depth, tile_samples) + 63) & ~63ull;
+  int waves = c->n_cus * 8 * WAVES_PER_BLOCK;  // upper bound on resident waves
+  size_t need = (size_t)waves * c->scratch_stride;
+  if (need > c->scratch_floats) {
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_floats = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_scratch, need * sizeof(float)));
+    c->scratch_floats = need;
+  }
+  c->scratch_waves = waves;
+  c->prepared = true;
+  return RT_OK;
+}
+
+int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids, hipStream_t s) {
+  int rc = prepare(c, flags);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const rt_camera &cam = c->cam;
+  RenderParams p{};
+  p.nodes = c->d_nodes;
+  p.prims = c->d_prims;
+  p.materials = c->d_materials;
+  p.lights = c->d_lights;
+  p.f6 = c->d_f6;
+  p.n_lights = c->n_lights;
+  p.n_grids = c->n_grids;
+  p.spp = c->spp;
+  p.has_root = c->has_root;
+  p.W = cam.img_w;
+  p.H = cam.img_h;
+  p.max_depth = cam.max_depth;
+  p.view_w = cam.view_w;
+  p.view_h = cam.view_h;
+  p.view_d = cam.view_d;
+  p.lens = cam.lens;
+  for (int i = 0; i < 3; ++i) {
+    p.eye[i] = cam.eye[i];
+    p.u[i] = cam.u[i];
+    p.v[i] = cam.v[i];
+    p.w[i] = cam.w[i];
+    p.ambient[i] = cam.ambient[i];
+  }
+  p.tile_w = c->tiling.tile_w;
+  p.tile_h = c->tiling.tile_h;
+  p.tiles_x = c->tiling.tiles_x;
+  p.tile_samples = c->tiling.tile_w * c->tiling.tile_h * c->spp;
+  p.rank = c->rank;
+  p.nranks = c->nranks;
+  p.n_local_tiles = c->tiling.n_local_tiles;
+  p.compact = compact;
+  p.rgb = d_out;
+  p.hit_ids = d_ids;
+  p.scratch = c->d_scratch;
+  p.scratch_stride = c->scratch_stride;
+  p.tile_counter = c->d_tile_counter;
+  p.stats = c->d_stats;
+  p.stack_depth = c->stack_depth;
+  p.trace_zero_weight = (flags & RT_FLAG_TRACE_ZERO_WEIGHT) ? 1 : 0;
+
+  LaunchCfg cfg{};
+  cfg.block = 64 * WAVES_PER_BLOCK;
+  cfg.lds_bytes = lds_bytes_for(c->stack_depth);
+  cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
+  cfg.count = (flags & RT_FLAG_COUNT_TESTS) != 0;
+  const bool fma = (flags & RT_FLAG_FMA) != 0;
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_bytes);
+  if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
+  per_cu = std::min(per_cu, 8);
+  int want = (c->tiling.n_local_tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  cfg.grid = std::max(1, std::min(c->n_cus * per_cu, want));
+  if (cfg.grid * WAVES_PER_BLOCK > c->scratch_waves)
+    return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
+
+  HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), s));
+  HIP_TRY(c, hipEventRecord(c->ev0, s));
+  if (fma) launch_render_fma(p, cfg, s);
+  else launch_render_strict(p, cfg, s);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev1, s));
+  c->timed = true;
+  return RT_OK;
+}
+
+int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (!st) return RT_OK;
+  std::memset(st, 0, sizeof *st);
+  unsigned long long h[8];
+  HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  st->rays_primary = h[0];
+  st->rays_shadow = h[1];
+  st->rays_reflection = h[2];
+  st->rays_refraction = h[3];
+  st->box_tests = h[4];
+  st->sphere_tests = h[5];
+  st->triangle_tests = h[6];
+  st->primary_hits = h[7];
+  if (c->timed) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st->ms_kernel = ms;
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_init(int device, rt_ctx **out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RT_ERR_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return RT_ERR_DEVICE;
+  rt_ctx *c = new rt_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete c;
+    return RT_ERR_DEVICE;
+  }
+  c->n_cus = prop.multiProcessorCount;
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipMalloc((void **)&c->d_tile_counter, 256) == hipSuccess &&
+            hipMalloc((void **)&c->d_stats, 256) == hipSuccess;
+  if (!ok) {
+    rt_shutdown(c);
+    return RT_ERR_DEVICE;
+  }
+  *out = c;
+  return RT_OK;
+}
+
+void rt_shutdown(rt_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
+                  c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *rt_last_error(rt_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
+  if (!c || !sc) return RT_ERR_INVALID;
+  if (sc->n_nodes < 0 || sc->n_refs < 0 || sc->n_spheres < 0 || sc->n_triangles < 0 ||
+      sc->n_materials < 0 || sc->n_lights < 0)
+    return fail(c, RT_ERR_INVALID, "negative count in rt_scene");
+  if ((sc->n_nodes && !sc->nodes) || (sc->n_refs && !sc->leaf_refs) || (sc->n_spheres && !sc->spheres) ||
+      (sc->n_triangles && !sc->triangles) || (sc->n_materials && !sc->materials) ||
+      (sc->n_lights && !sc->lights))
+    return fail(c, RT_ERR_INVALID, "null array with non-zero count in rt_scene");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->have_scene = false;
+  c->prepared = false;
+  Repack rp;
+  rp.sc = sc;
+  rp.seen.assign((size_t)sc->n_nodes, 0);
+  // pseudo root (rt_device.h): left = real root, right = none
+  rp.nodes.assign(16, 0.0f);
+  int root_ref = REF_NONE;
+  if (sc->n_nodes > 0) {
+    root_ref = rp.visit(0, 1);
+    if (!rp.err.empty()) return fail(c, RT_ERR_INVALID, "invalid BVH: %s", rp.err.c_str());
+    std::memcpy(&rp.nodes[0], &sc->nodes[0].xmin, 24);
+  }
+  Repack::put_i(&rp.nodes[12], root_ref);
+  Repack::put_i(&rp.nodes[13], REF_NONE);
+  if (rp.max_depth > 64)
+    return fail(c, RT_ERR_LIMIT, "BVH depth %d exceeds the traversal stack limit of 64", rp.max_depth);
+  int rc;
+  if ((rc = upload(c, &c->d_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
+  if ((rc = upload(c, &c->d_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
+  if ((rc = upload(c, &c->d_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
+  if ((rc = upload(c, &c->d_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
+  c->n_lights = sc->n_lights;
+  c->has_root = sc->n_nodes > 0;
+  c->tree_depth = rp.max_depth;
+  c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
+  if (!c || !cam) return RT_ERR_INVALID;
+  if (cam->img_w < 1 || cam->img_h < 1 || cam->img_w > 65536 || cam->img_h > 65536)
+    return fail(c, RT_ERR_INVALID, "image size %dx%d out of range", cam->img_w, cam->img_h);
+  if (cam->aa < 1 || cam->aa > 32) return fail(c, RT_ERR_INVALID, "aa=%d out of range [1,32]", cam->aa);
+  if (cam->max_depth < 0 || cam->max_depth > MAX_DEPTH)
+    return fail(c, RT_ERR_LIMIT, "max_depth=%d out of range [0,%d]", cam->max_depth, MAX_DEPTH);
+  c->cam = *cam;
+  c->have_cam = true;
+  c->prepared = false;
+  return RT_OK;
+}
+
+int rt_set_samples(rt_ctx *c, const float *f6, int32_t n_grids, int32_t spp) {
+  if (!c || !f6) return RT_ERR_INVALID;
+  if (n_grids < 1 || spp < 1 || spp > 1024) return fail(c, RT_ERR_INVALID, "bad sample table shape");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = upload(c, &c->d_f6, f6, (size_t)n_grids * spp * 6 * sizeof(float));
+  if (rc) return rc;
+  c->n_grids = n_grids;
+  c->spp = spp;
+  c->have_samples = true;
+  c->prepared = false;
+  return RT_OK;
+}
+
+int rt_set_partition(rt_ctx *c, int32_t rank, int32_t nranks) {
+  if (!c) return RT_ERR_INVALID;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, RT_ERR_INVALID, "bad partition %d/%d", rank, nranks);
+  c->rank = rank;
+  c->nranks = nranks;
+  c->prepared = false;
+  return RT_OK;
+}
+
+int rt_get_tiling(rt_ctx *c, rt_tiling *out) {
+  if (!c || !out) return RT_ERR_INVALID;
+  if (!c->have_cam || !c->have_samples) return fail(c, RT_ERR_STATE, "camera and samples must be set first");
+  compute_tiling(c);
+  *out = c->tiling;
+  return RT_OK;
+}
+
+int rt_render_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_ids, void *stream) {
+  if (!c || !d_rgb) return RT_ERR_INVALID;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  return launch(c, flags, d_rgb, 0, d_ids, s);
+}
+
+int rt_render_tiles_async(rt_ctx *c, uint32_t flags, float *d_tiles, void *stream) {
+  if (!c || !d_tiles) return RT_ERR_INVALID;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  return launch(c, flags, d_tiles, 1, nullptr, s);
+}
+
+int rt_assemble_async(rt_ctx *c, const float *d_gathered, int32_t nranks, size_t stride_floats,
+                      float *d_rgb, void *stream) {
+  if (!c || !d_gathered || !d_rgb || nranks < 1) return RT_ERR_INVALID;
+  if (!c->have_cam || !c->have_samples) return fail(c, RT_ERR_STATE, "camera and samples must be set first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  compute_tiling(c);
+  const rt_tiling &t = c->tiling;
+  size_t tile_floats = (size_t)t.tile_w * t.tile_h * 3;
+  size_t max_local = (size_t)(t.n_tiles + nranks - 1) / nranks;
+  if (stride_floats < max_local * tile_floats)
+    return fail(c, RT_ERR_INVALID, "stride_floats %zu smaller than a rank's tile buffer %zu", stride_floats,
+                max_local * tile_floats);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  size_t total = (size_t)t.n_tiles * t.tile_w * t.tile_h;
+  int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(256), 0, s, d_gathered, nranks, stride_floats, d_rgb,
+                     c->cam.img_w, c->cam.img_h, t.tile_w, t.tile_h, t.tiles_x, t.n_tiles);
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, void *stream) {
+  if (!c || !d_rgb || !d_rgb8) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (n == 0) return RT_OK;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, s, d_rgb, d_rgb8, n);
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_collect(rt_ctx *c, void *stream, rt_stats *st) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return collect(c, stream ? (hipStream_t)stream : c->stream, st);
+}
+
+int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_stats *st) {
+  if (!c || !rgb_out) return RT_ERR_INVALID;
+  int rc = prepare(c, flags);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipEvent_t t0, t1;
+  HIP_TRY(c, hipEventCreate(&t0));
+  HIP_TRY(c, hipEventCreate(&t1));
+  size_t npx = (size_t)c->cam.img_w * c->cam.img_h;
+  if (c->d_rgb_floats < npx * 3) {
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    c->d_rgb = nullptr;
+    c->d_rgb_floats = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgb, npx * 3 * sizeof(float)));
+    c->d_rgb_floats = npx * 3;
+  }
+  if (ids_out && c->d_ids_count < npx * c->spp) {
+    if (c->d_ids) (void)hipFree(c->d_ids);
+    c->d_ids = nullptr;
+    c->d_ids_count = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_ids, npx * c->spp * sizeof(uint32_t)));
+    c->d_ids_count = npx * c->spp;
+  }
+  HIP_TRY(c, hipEventRecord(t0, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_rgb, 0, npx * 3 * sizeof(float), c->stream));
+  if (ids_out) HIP_TRY(c, hipMemsetAsync(c->d_ids, 0xff, npx * c->spp * sizeof(uint32_t), c->stream));
+  rc = launch(c, flags, c->d_rgb, 0, ids_out ? c->d_ids : nullptr, c->stream);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (ids_out)
+    HIP_TRY(c, hipMemcpyAsync(ids_out, c->d_ids, npx * c->spp * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              c->stream));
+  HIP_TRY(c, hipEventRecord(t1, c->stream));
+  rc = collect(c, c->stream, st);
+  if (rc) return rc;
+  if (st) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, t0, t1));
+    st->ms_total = ms;
+  }
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// rt_device.h -- private interface between the host side of librt_mi355x.so
+// (rt_api.cpp) and its HIP kernels (rt_kernels.inl, compiled twice: strict / fma).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_mi355x.h"
+
+namespace rtdev {
+
+// ---- device-side scene layout (HBM; tiny scenes live in L1/L2) -------------
+//
+// Node record, 64 B = 4 x float4.  An INNER node carries the boxes of BOTH its
+// children, so one 64-B fetch decides both hitsBox tests
+// (BoundingVolumeHierarchy.hs:191-204) that hitBVH (RayTracer.hs:404-412) performs
+// on entering the children:
+//   f[0..5]   left  child box  xmin xmax ymin ymax zmin zmax
+//   f[6..11]  right child box
+//   i[12]     left  child ref      i[13] right child ref
+//   ref >= 0: inner node index;  ref < 0, ref != REF_NONE: leaf, first prim = -1-ref
+// Record 0 is a pseudo root whose left child is the real root (so the root's own
+// box is tested like every other) and whose right child is REF_NONE.
+constexpr int REF_NONE = INT32_MIN;
+constexpr int NODE_F4 = 4;
+
+// Primitive record, 64 B = 4 x float4, stored in depth-first leaf order; inside a
+// leaf the object list is stored REVERSED, so that among hits with equal t the
+// larger record index is the one hitBVH's `max` / hits' strict `<` would keep
+// (right subtree wins, first object of a leaf wins: RayTracer.hs:383-402,410).
+//   triangle: f[0..2] A   f[3..5] A-B   f[6..8] A-C   f[9..11] N
+//   sphere  : f[0..2] C   f[3] r        f[4] r*r
+//   i[12] kind (0 sphere, 1 triangle)  i[13] material  i[14] object id
+//   i[15] number of records in this leaf (valid in the leaf's first record)
+constexpr int PRIM_F4 = 4;
+
+constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
+constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
+constexpr int TAG_SLOTS = 256;  // LDS tag table per wave (conflict-free accumulation)
+constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct RenderParams {
+  const float4 *nodes;
+  const float4 *prims;
+  const float *materials;  // 12 floats each, rt_material order
+  const float *lights;     // 12 floats each, rt_light order
+  const float *f6;         // [n_grids][spp][6]
+  int n_lights, n_grids, spp, has_root;
+  // camera (rt_camera)
+  int W, H, max_depth, pad0;
+  float view_w, view_h, view_d, lens;
+  float eye[3], u[3], v[3], w[3], ambient[3];
+  // tiling / partition
+  int tile_w, tile_h, tiles_x, tile_samples;
+  int rank, nranks, n_local_tiles, compact;
+  // outputs
+  float *rgb;         // full frame [H*W*3] or compact [n_local_tiles][tile_h][tile_w][3]
+  uint32_t *hit_ids;  // may be null
+  // per-wave scratch in HBM: ray queues + per-sample accumulators
+  float *scratch;
+  unsigned long long scratch_stride;  // floats per wave
+  unsigned *tile_counter;
+  unsigned long long *stats;  // 8 counters (rt_stats order)
+  int stack_depth, trace_zero_weight;
+};
+
+struct LaunchCfg {
+  int grid, block;
+  size_t lds_bytes;
+  bool prune, count;
+};
+
+// one per arithmetic mode (separate translation units, different -ffp-contract)
+void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
+void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
+int occupancy_strict(bool prune, bool count, size_t lds_bytes);
+int occupancy_fma(bool prune, bool count, size_t lds_bytes);
+
+inline size_t lds_bytes_for(int stack_depth) {
+  return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + TAG_SLOTS + 32) * 4;
+}
+inline unsigned long long scratch_floats_per_wave(int max_depth, int tile_samples) {
+  int levels = max_depth > 1 ? max_depth - 1 : 0;  // level 1 (primary) is never queued
+  return (unsigned long long)levels * QFIELDS * QCAP + 3ull * (unsigned long long)tile_samples;
+}
+
+}  // namespace rtdev

@@ -1,0 +1,14 @@
+// FMA build of the trace/shade kernels: the same source compiled with
+// -ffp-contract=fast, so the Geometry3 vector math contracts to v_fma_f32
+// (BASELINE.json north_star).  Selected with RT_FLAG_FMA.
+#define RT_NS fma
+#include "rt_kernels.inl"
+
+namespace rtdev {
+void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
+  fma::launch(p, cfg, s);
+}
+int occupancy_fma(bool prune, bool count, size_t lds_bytes) {
+  return fma::occupancy(prune, count, lds_bytes);
+}
+}  // namespace rtdev

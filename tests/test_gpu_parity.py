@@ -1,0 +1,130 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  The oracle is a restatement of the reference (PARITY UNPINNED: the
+reference has no tests or golden vectors, see oracle/rt_oracle.c)."""
+import numpy as np
+import pytest
+
+from conftest import make_world
+
+pytestmark = pytest.mark.gpu
+
+
+def psnr8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float(np.mean(d * d))
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.fixture(scope="module")
+def renderer(rt):
+    r = rt.Renderer(0)
+    yield r
+    r.close()
+
+
+def run_both(rt, oracle, renderer, world, seed, gpu_flags, oracle_flags):
+    grids = rt.generate_grids(seed, world.width + 10, world.camera.aa)
+    renderer.set_partition(0, 1)
+    renderer.set_world(world)
+    renderer.set_samples(grids)
+    g_rgb, g_ids, g_st = renderer.render(gpu_flags, want_hit_ids=True)
+    o_rgb, o_ids, o_st = oracle.render(world, grids, oracle_flags)
+    return (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st)
+
+
+def check_image(rt, g_rgb, o_rgb, tol8=1, min_psnr=50.0):
+    finite = np.isfinite(o_rgb).all(axis=1)
+    g8, o8 = rt.quantize(g_rgb)[finite], rt.quantize(o_rgb)[finite]
+    d = np.abs(g8.astype(np.int32) - o8.astype(np.int32))
+    # tolerance stated by BASELINE.json north_star: |delta| <= 1/255 on 8-bit, PSNR >= 50 dB
+    assert d.max() <= tol8, f"max 8-bit delta {d.max()} at {np.argwhere(d > tol8)[:5]}"
+    assert psnr8(g8, o8) >= min_psnr
+    return d
+
+
+SCENES = [("bench1", 16), ("bench2", 4), ("bench3", 4), ("bench4", 16), ("bench5", 16)]
+
+
+@pytest.mark.parametrize("name,rpp", SCENES)
+def test_strict_exact_traversal_matches_oracle(rt, oracle, renderer, name, rpp):
+    """STRICT arithmetic + reference traversal + every ray traced: hit ids and ray
+    counts must be identical, colours equal up to libm powf/expf and summation order."""
+    w = make_world(rt, name, 160, 120, rpp, lens=0.05 if name == "bench4" else None)
+    flags = rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 7, flags, 0)
+    assert o_st.nan_hits == 0
+    assert int((g_ids != o_ids).sum()) == 0
+    assert g_st.rays_primary == o_st.rays_primary
+    assert g_st.rays_shadow == o_st.rays_shadow
+    assert g_st.rays_reflection == o_st.rays_reflection
+    assert g_st.rays_refraction == o_st.rays_refraction
+    assert g_st.primary_hits == o_st.primary_hits
+    check_image(rt, g_rgb, o_rgb)
+    fin = np.isfinite(o_rgb)
+    assert np.allclose(g_rgb[fin], o_rgb[fin], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,rpp", SCENES)
+def test_default_mode_matches_oracle(rt, oracle, renderer, name, rpp):
+    """Default GPU mode (strict arithmetic, pruned ordered traversal, zero-weight rays
+    culled) against the oracle with the same culling policy."""
+    w = make_world(rt, name, 160, 120, rpp, lens=0.05 if name == "bench4" else None)
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(
+        rt, oracle, renderer, w, 11, 0, oracle.FLAG_CULL_ZERO_WEIGHT)
+    mism = int((g_ids != o_ids).sum())
+    print(f"{name}: primary hit-id mismatches {mism} / {g_ids.size}")
+    assert mism == 0
+    assert g_st.rays_total == o_st.rays_total
+    check_image(rt, g_rgb, o_rgb)
+
+
+def test_counted_tests_match_oracle(rt, oracle, renderer):
+    """With the reference's traversal policy the GPU performs exactly the oracle's
+    number of box / sphere / triangle tests (integers must agree)."""
+    w = make_world(rt, "bench1", 96, 72, 4)
+    flags = rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT | rt.FLAG_COUNT_TESTS
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 3, flags, 0)
+    assert g_st.sphere_tests == o_st.sphere_tests
+    assert g_st.triangle_tests == o_st.triangle_tests
+    # the oracle tests a node's own box on entry (one test per visited node); the device
+    # tests both children of a visited inner node: same predicates, counted per child
+    assert g_st.box_tests >= o_st.box_tests
+
+
+def test_fma_mode_reports_mismatch(rt, oracle, renderer):
+    w = make_world(rt, "bench1", 160, 120, 16)
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(
+        rt, oracle, renderer, w, 5, rt.FLAG_FMA, oracle.FLAG_CULL_ZERO_WEIGHT)
+    mism = int((g_ids != o_ids).sum())
+    g8, o8 = rt.quantize(g_rgb), rt.quantize(o_rgb)
+    d = np.abs(g8.astype(np.int32) - o8.astype(np.int32))
+    print(f"FMA mode: hit-id mismatches {mism}/{g_ids.size}, 8-bit max delta {d.max()}, "
+          f"pixels off by >1: {(d.max(axis=1) > 1).sum()}, PSNR {psnr8(g8, o8):.1f} dB")
+    assert mism <= g_ids.size // 1000
+
+
+def test_partition_tiles_assemble_to_full_frame(rt, renderer):
+    """Static interleaved tile partition: the tiles of 3 virtual ranks assembled with
+    rt_assemble_async are byte-identical to the single-rank frame."""
+    import torch
+    w = make_world(rt, "bench1", 200, 150, 4)
+    grids = rt.generate_grids(9, w.width + 10, w.camera.aa)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    renderer.set_partition(0, 1)
+    full, _, _ = renderer.render(0)
+    n = 3
+    til = renderer.tiling()
+    tile_floats = til.tile_w * til.tile_h * 3
+    stride = ((til.n_tiles + n - 1) // n) * tile_floats
+    gathered = torch.zeros(n * stride, dtype=torch.float32, device="cuda:0")
+    for r in range(n):
+        renderer.set_partition(r, n)
+        renderer.render_tiles_async(gathered.data_ptr() + r * stride * 4)
+        renderer.collect()
+    out = torch.zeros(w.height * w.width * 3, dtype=torch.float32, device="cuda:0")
+    renderer.set_partition(0, n)
+    renderer.assemble_async(gathered.data_ptr(), n, stride, out.data_ptr())
+    renderer.collect()
+    renderer.set_partition(0, 1)
+    assert np.array_equal(out.cpu().numpy().reshape(-1, 3), full)
