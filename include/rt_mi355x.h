@@ -146,7 +146,8 @@ typedef struct rt_stats {
   uint64_t sphere_tests;
   uint64_t triangle_tests;
   uint64_t primary_hits;
-  uint64_t reserved[4];
+  uint64_t shaded_hits;       /* closest hits of any generation (shaded points) */
+  uint64_t reserved[3];
   double ms_kernel;           /* trace/shade kernel, HIP events on its stream */
   double ms_total;            /* whole call incl. copies                      */
 } rt_stats;

@@ -78,7 +78,7 @@ class Camera(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_shadow", u64), ("rays_reflection", u64),
                 ("rays_refraction", u64), ("box_tests", u64), ("sphere_tests", u64),
-                ("triangle_tests", u64), ("primary_hits", u64), ("reserved", u64 * 4),
+                ("triangle_tests", u64), ("primary_hits", u64), ("shaded_hits", u64), ("reserved", u64 * 3),
                 ("ms_kernel", C.c_double), ("ms_total", C.c_double)]
 
     @property
@@ -165,6 +165,30 @@ def host_lib() -> C.CDLL:
     return _host
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (soname libamdhip64.so.7) and ask for it as "libamdhip64.so"; if
+    librt_mi355x.so pulled in /opt/rocm's copy first, a later `import torch` would load
+    a second runtime that sees no GPU.  When a torch wheel is installed (and not yet
+    imported) load ITS runtime first, so both sides share it.  Plumbing only."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def device_lib() -> C.CDLL:
     """The HIP library.  Fails loudly when it has not been built (no fallback)."""
     global _dev
@@ -172,6 +196,7 @@ def device_lib() -> C.CDLL:
         if not os.path.exists(DEVICE_LIB_PATH):
             raise RtError(f"{DEVICE_LIB_PATH} missing: the HIP extension is not built; there is "
                           "no CPU fallback for the trace/shade path")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(DEVICE_LIB_PATH)
         vp = C.c_void_p
         L.rt_init.argtypes = [C.c_int, C.POINTER(vp)]

@@ -312,7 +312,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
 
   HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned), s));
-  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
   HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
@@ -326,7 +326,7 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   HIP_TRY(c, hipStreamSynchronize(s));
   if (!st) return RT_OK;
   std::memset(st, 0, sizeof *st);
-  unsigned long long h[8];
+  unsigned long long h[9];
   HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
   st->rays_primary = h[0];
   st->rays_shadow = h[1];
@@ -336,6 +336,7 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   st->sphere_tests = h[5];
   st->triangle_tests = h[6];
   st->primary_hits = h[7];
+  st->shaded_hits = h[8];
   if (c->timed) {
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -61,7 +61,7 @@ struct RenderParams {
   float *scratch;
   unsigned long long scratch_stride;  // floats per wave
   unsigned *tile_counter;
-  unsigned long long *stats;  // 8 counters (rt_stats order)
+  unsigned long long *stats;  // 9 counters (rt_stats order)
   int stack_depth, trace_zero_weight;
 };
 

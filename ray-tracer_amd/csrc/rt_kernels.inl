@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P) {
   const int tile_px = P.tile_w * P.tile_h;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  unsigned long long n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0;
+  unsigned long long n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
   Counters cn = {0, 0, 0};
 
   for (;;) {
@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P) {
       int p;
       traverse<false, PRUNE, COUNT>(P, stack, lane, active, o, d, 0.0f, t, p, cn);
       const bool hit = active && p >= 0;
+      n_hits += __popcll(__ballot(hit));
 
       if (level == 1) {
         n_phits += __popcll(__ballot(hit));
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P) {
     atomicAdd(&P.stats[2], n_refl);
     atomicAdd(&P.stats[3], n_refr);
     atomicAdd(&P.stats[7], n_phits);
+    atomicAdd(&P.stats[8], n_hits);
   }
   if (COUNT) {
     atomicAdd(&P.stats[4], (unsigned long long)cn.box);
