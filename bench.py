@@ -40,7 +40,7 @@ WORKLOADS = {
     # name: (scene, config name, width, height, (view w,h,d), rays per pixel, lens)
     "c1": ("bench1", "bench1", 800, 600, (8, 6, 7), 1, None),
     "c2": ("bench1", "bench1", 1920, 1080, (16, 9, 10), 16, None),
-    "c3": ("mesh:100000", "bench6", 1920, 1080, (16, 9, 10), 4, None),
+    "c3": ("mesh:100000", "mesh", 1920, 1080, (16, 9, 10), 4, None),
     "c4-glossy": ("bench5", "bench5", 1920, 1080, (16, 9, 10), 64, None),
     "c4-dof": ("bench4", "bench4", 1920, 1080, (16, 9, 10), 64, 0.05),
 }

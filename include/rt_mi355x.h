@@ -147,7 +147,9 @@ typedef struct rt_stats {
   uint64_t triangle_tests;
   uint64_t primary_hits;
   uint64_t shaded_hits;       /* closest hits of any generation (shaded points) */
-  uint64_t reserved[3];
+  uint64_t wave_ticks_sum;    /* diagnostics, 100 MHz ticks: sum / max of the lifetimes  */
+  uint64_t wave_ticks_max;    /* of the persistent waves, and their number (load balance) */
+  uint64_t n_waves;
   double ms_kernel;           /* trace/shade kernel, HIP events on its stream */
   double ms_total;            /* whole call incl. copies                      */
 } rt_stats;

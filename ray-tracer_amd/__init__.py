@@ -29,7 +29,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "librt_host.so")
-DEVICE_LIB_PATH = os.path.join(LIB_DIR, "librt_mi355x.so")
+DEVICE_LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(LIB_DIR, "librt_mi355x.so")
 
 # --------------------------------------------------------------------------
 # PODs of include/rt_mi355x.h / include/rt_host.h
@@ -78,7 +78,8 @@ class Camera(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_shadow", u64), ("rays_reflection", u64),
                 ("rays_refraction", u64), ("box_tests", u64), ("sphere_tests", u64),
-                ("triangle_tests", u64), ("primary_hits", u64), ("shaded_hits", u64), ("reserved", u64 * 3),
+                ("triangle_tests", u64), ("primary_hits", u64), ("shaded_hits", u64),
+                ("wave_ticks_sum", u64), ("wave_ticks_max", u64), ("n_waves", u64),
                 ("ms_kernel", C.c_double), ("ms_total", C.c_double)]
 
     @property
@@ -86,7 +87,7 @@ class Stats(C.Structure):
         return (self.rays_primary + self.rays_shadow + self.rays_reflection + self.rays_refraction)
 
     def as_dict(self) -> dict:
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
         d["rays_total"] = self.rays_total
         return d
 

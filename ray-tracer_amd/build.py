@@ -42,11 +42,13 @@ def build_host(force=False):
     return out
 
 
-def build_device(force=False):
+def build_device(force=False, defines=(), tag=""):
+    """tag != "" builds an experiment variant lib/librt_mi355x<tag>.so with extra -D flags
+    (select it at run time with RT_MI355X_LIB=<path>)."""
     os.makedirs(LIB, exist_ok=True)
-    obj = os.path.join(HERE, "build")
+    obj = os.path.join(HERE, "build" + tag)
     os.makedirs(obj, exist_ok=True)
-    out = os.path.join(LIB, "librt_mi355x.so")
+    out = os.path.join(LIB, f"librt_mi355x{tag}.so")
     common = [os.path.join(CSRC, "rt_device.h"), os.path.join(INC, "rt_mi355x.h")]
     kern = os.path.join(CSRC, "rt_kernels.inl")
     units = [
@@ -55,6 +57,7 @@ def build_device(force=False):
         ("rt_api", ["-ffp-contract=off"], []),
     ]
     base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
+    base += ["-D" + d for d in defines]
     objs = []
     relink = force
     for name, flags, extra in units:
@@ -74,4 +77,9 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all("--force" in sys.argv)
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
+    if tags:
+        build_device(True, defs, tags[0])
+    else:
+        build_all("--force" in sys.argv)

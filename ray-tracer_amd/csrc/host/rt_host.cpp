@@ -509,11 +509,12 @@ void mesh_torus(rth_scene &s, V3 c, float R, float r, int nu, int nv, int mat) {
 }
 
 // Tessellated floor, normals +y.
-void mesh_floor(rth_scene &s, float y, float half, int n, int mat_a, int mat_b) {
+void mesh_floor(rth_scene &s, V3 O, float y, float half, int n, int mat_a, int mat_b) {
   float step = 2 * half / (float)n;
+  y += O.y;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) {
-      float x0 = -half + step * (float)i, z0 = -half + step * (float)j;
+      float x0 = O.x - half + step * (float)i, z0 = O.z - half + step * (float)j;
       float x1 = x0 + step, z1 = z0 + step;
       int m = ((i + j) & 1) ? mat_a : mat_b;
       s.mesh_triangle(v3(x0, y, z0), v3(x0, y, z1), v3(x1, y, z1), m);
@@ -524,11 +525,19 @@ void mesh_floor(rth_scene &s, float y, float half, int n, int mat_a, int mat_b) 
 // Station-style triangle mesh (stand-in for the missing station.obj, Main.hs:235):
 // reflective hub (illum 3), torus ring (illum 3), refractive pods (illum 6 and 4),
 // spokes and a checkered floor (illum 2); lights of bench6World (Main.hs:239-246).
+//
+// The whole scene is translated by (+20,+20,+20) into the positive octant: the
+// reference's surfaceArea computes `abs r - l` (BoundingVolumeHierarchy.hs:91-93), which
+// is the true extent only when the upper bounds are non-negative; around the origin the
+// faithful sahBVH degenerates into leaves of thousands of triangles (measured: 3939),
+// which would benchmark the quirk rather than the traversal.  Config "mesh" moves the
+// camera of bench6Config by the same offset.
 void build_mesh(rth_scene &s, int target_tris) {
+  const V3 O = v3(20, 20, 20);
   const float lc[3] = {0.5f, 0.5f, 0.5f};
   const float lp[8][3] = {{10, 20, 0},  {-10, 20, 0},  {0, 20, 10},  {0, 20, -10},
                           {0, -20, 10}, {0, -20, -10}, {10, -20, 0}, {-10, -20, 0}};
-  for (int i = 0; i < 8; ++i) s.light(get(lp[i]), v3(0, 0, 0), v3(0, 0, 0), get(lc));
+  for (int i = 0; i < 8; ++i) s.light(add(O, get(lp[i])), v3(0, 0, 0), v3(0, 0, 0), get(lc));
   const float grey[3] = {0.6f, 0.6f, 0.65f}, white[3] = {1, 1, 1}, blue[3] = {0.2f, 0.3f, 0.9f};
   const float gold[3] = {1, 0.842f, 0.1f}, dark[3] = {0.15f, 0.15f, 0.2f}, black[3] = {0, 0, 0};
   const float red[3] = {0.9f, 0.15f, 0.1f}, half[3] = {0.5f, 0.5f, 0.5f};
@@ -544,15 +553,15 @@ void build_mesh(rth_scene &s, int target_tris) {
   int nr = std::max(4, (int)sqrtf(0.40f * (float)target_tris / 8.0f));   // 2*nu*nv, nu = 4 nv
   int np = std::max(4, (int)sqrtf(0.05f * (float)target_tris / 4.0f));
   int nf = std::max(2, (int)sqrtf(0.20f * (float)target_tris / 2.0f));
-  mesh_uv_sphere(s, v3(0, 0, 0), 3, 2 * nh, nh, m_hub);
-  mesh_torus(s, v3(0, 0, 0), 8, 1, 4 * nr, nr, m_ring);
-  mesh_uv_sphere(s, v3(8, 2.5f, 0), 1.5f, 2 * np, np, m_pod);
-  mesh_uv_sphere(s, v3(-8, 2.5f, 0), 1.5f, 2 * np, np, m_pod2);
-  mesh_uv_sphere(s, v3(0, 2.5f, 8), 1.5f, 2 * np, np, m_pod);
-  mesh_uv_sphere(s, v3(0, 2.5f, -8), 1.5f, 2 * np, np, m_pod2);
-  s.parallelepiped(v3(-7.5f, -0.25f, -0.25f), v3(15, 0, 0), v3(0, 0.5f, 0), v3(0, 0, 0.5f), m_spoke);
-  s.parallelepiped(v3(-0.25f, -0.25f, -7.5f), v3(0.5f, 0, 0), v3(0, 0.5f, 0), v3(0, 0, 15), m_spoke);
-  mesh_floor(s, -3, 16, nf, m_fa, m_fb);
+  mesh_uv_sphere(s, add(O, v3(0, 0, 0)), 3, 2 * nh, nh, m_hub);
+  mesh_torus(s, add(O, v3(0, 0, 0)), 8, 1, 4 * nr, nr, m_ring);
+  mesh_uv_sphere(s, add(O, v3(8, 2.5f, 0)), 1.5f, 2 * np, np, m_pod);
+  mesh_uv_sphere(s, add(O, v3(-8, 2.5f, 0)), 1.5f, 2 * np, np, m_pod2);
+  mesh_uv_sphere(s, add(O, v3(0, 2.5f, 8)), 1.5f, 2 * np, np, m_pod);
+  mesh_uv_sphere(s, add(O, v3(0, 2.5f, -8)), 1.5f, 2 * np, np, m_pod2);
+  s.parallelepiped(add(O, v3(-7.5f, -0.25f, -0.25f)), v3(15, 0, 0), v3(0, 0.5f, 0), v3(0, 0, 0.5f), m_spoke);
+  s.parallelepiped(add(O, v3(-0.25f, -0.25f, -7.5f)), v3(0.5f, 0, 0), v3(0, 0.5f, 0), v3(0, 0, 15), m_spoke);
+  mesh_floor(s, O, -3, 16, nf, m_fa, m_fb);
 }
 
 const struct {
@@ -566,6 +575,8 @@ const struct {
     {"bench4", {800, 600, 8, 6, 7, 6, 25, 0.05f, {0, 1, 0}, {50, 5, 0}, {0, 0, 0}}},
     {"bench5", {800, 600, 8, 6, 7, 6, 25, 0.0f, {0, 1, 0}, {20, 0, 0}, {0, 0, 0}}},
     {"bench6", {80, 60, 8, 6, 8, 6, 4, 0.0f, {0, 1, 0}, {18, 12, 18}, {0, 0, 0}}},
+    // bench6Config moved with the generated mesh (see build_mesh)
+    {"mesh", {80, 60, 8, 6, 8, 6, 4, 0.0f, {0, 1, 0}, {38, 32, 38}, {20, 20, 20}}},
     // scene1C (Main.hs:141-142)
     {"scene1", {800, 600, 8, 6, 7, 6, 25, 0.0f, {0, 1, 0}, {10, 0, 0}, {0, 0, 0}}},
 };

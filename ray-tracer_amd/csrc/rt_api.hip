@@ -26,7 +26,7 @@ struct rt_ctx {
   // scene
   float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
-  int n_lights = 0, has_root = 0, tree_depth = 0;
+  int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   bool have_scene = false;
   // camera / samples
   rt_camera cam{};
@@ -44,6 +44,8 @@ struct rt_ctx {
   int scratch_waves = 0;
   unsigned *d_tile_counter = nullptr;
   unsigned long long *d_stats = nullptr;
+  long long *d_acc = nullptr;
+  size_t acc_samples = 0;
   // staging for the host-pointer form
   float *d_rgb = nullptr;
   size_t d_rgb_floats = 0;
@@ -235,9 +237,18 @@ int prepare(rt_ctx *c, uint32_t flags) {
   compute_tiling(c);
   c->stack_depth = std::max(4, (c->tree_depth + 3) & ~3);
   int tile_samples = c->tiling.tile_w * c->tiling.tile_h * c->spp;
-  c->scratch_stride = (scratch_floats_per_wave(c->cam.max_depth, tile_samples) + 63) & ~63ull;
+  c->scratch_stride = (scratch_floats_per_wave(c->cam.max_depth) + 63) & ~63ull;
+  (void)tile_samples;
+  size_t need_samples = (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h;  // pixels
+  if (need_samples > c->acc_samples) {
+    if (c->d_acc) (void)hipFree(c->d_acc);
+    c->d_acc = nullptr;
+    c->acc_samples = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_acc, need_samples * 3 * sizeof(long long)));
+    c->acc_samples = need_samples;
+  }
   int waves = c->n_cus * 8 * WAVES_PER_BLOCK;  // upper bound on resident waves
-  size_t need = (size_t)waves * c->scratch_stride;
+  size_t need = std::max<size_t>(64, (size_t)waves * c->scratch_stride);
   if (need > c->scratch_floats) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     c->d_scratch = nullptr;
@@ -265,6 +276,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.n_grids = c->n_grids;
   p.spp = c->spp;
   p.has_root = c->has_root;
+  p.boxes_safe = c->boxes_safe;
   p.W = cam.img_w;
   p.H = cam.img_h;
   p.max_depth = cam.max_depth;
@@ -291,6 +303,11 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.hit_ids = d_ids;
   p.scratch = c->d_scratch;
   p.scratch_stride = c->scratch_stride;
+  p.acc = c->d_acc;
+  p.px_per_packet = std::max(1, 64 / c->spp);
+  p.chunks_per_packet = (c->spp + 63) / 64;
+  p.groups_per_tile = (c->tiling.tile_w * c->tiling.tile_h + p.px_per_packet - 1) / p.px_per_packet;
+  p.n_packets = c->tiling.n_local_tiles * p.groups_per_tile;
   p.tile_counter = c->d_tile_counter;
   p.stats = c->d_stats;
   p.stack_depth = c->stack_depth;
@@ -306,12 +323,21 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
                    : occupancy_strict(cfg.prune, cfg.count, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
-  int want = (c->tiling.n_local_tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   cfg.grid = std::max(1, std::min(c->n_cus * per_cu, want));
   if (cfg.grid * WAVES_PER_BLOCK > c->scratch_waves)
     return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
 
-  HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned), s));
+  p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
+  p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
+  {
+    auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
+    long long n = std::max(1, p.packets_per_shard);
+    long long m = std::max<long long>(1, (long long)(0.6180339887 * (double)n));
+    while (gcd(m, n) != 1) ++m;
+    p.scatter_mul = m % n ? m % n : 1;
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
   HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
@@ -326,7 +352,7 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   HIP_TRY(c, hipStreamSynchronize(s));
   if (!st) return RT_OK;
   std::memset(st, 0, sizeof *st);
-  unsigned long long h[9];
+  unsigned long long h[12];
   HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
   st->rays_primary = h[0];
   st->rays_shadow = h[1];
@@ -337,6 +363,9 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   st->triangle_tests = h[6];
   st->primary_hits = h[7];
   st->shaded_hits = h[8];
+  st->wave_ticks_sum = h[9];
+  st->wave_ticks_max = h[10];
+  st->n_waves = h[11];
   if (c->timed) {
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -367,7 +396,7 @@ int rt_init(int device, rt_ctx **out) {
   c->n_cus = prop.multiProcessorCount;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipMalloc((void **)&c->d_tile_counter, 256) == hipSuccess &&
+            hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
             hipMalloc((void **)&c->d_stats, 256) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
@@ -382,7 +411,7 @@ void rt_shutdown(rt_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
-                  c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids};
+                  c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -428,6 +457,14 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   c->n_lights = sc->n_lights;
   c->has_root = sc->n_nodes > 0;
   c->tree_depth = rp.max_depth;
+  c->boxes_safe = 1;
+  for (int i = 0; i < sc->n_nodes && c->boxes_safe; ++i) {
+    const float *b = &sc->nodes[i].xmin;
+    for (int k = 0; k < 6; ++k) {
+      float a = std::fabs(b[k]);
+      if (!(b[k] == 0.0f || (a >= 1.4551915228366852e-11f && a <= 5.764607523034235e17f))) c->boxes_safe = 0;
+    }
+  }
   c->have_scene = true;
   return RT_OK;
 }

@@ -39,6 +39,7 @@ constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
 constexpr int TAG_SLOTS = 256;  // LDS tag table per wave (conflict-free accumulation)
 constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)
 
 struct RenderParams {
   const float4 *nodes;
@@ -57,12 +58,18 @@ struct RenderParams {
   // outputs
   float *rgb;         // full frame [H*W*3] or compact [n_local_tiles][tile_h][tile_w][3]
   uint32_t *hit_ids;  // may be null
-  // per-wave scratch in HBM: ray queues + per-sample accumulators
+  // per-wave scratch in HBM: the ray queues
   float *scratch;
   unsigned long long scratch_stride;  // floats per wave
-  unsigned *tile_counter;
-  unsigned long long *stats;  // 9 counters (rt_stats order)
+  long long *acc;                     // [n_local_tiles * tile_w * tile_h][3] fixed-point pixel sums
+  unsigned *tile_counter;             // PACKET_SHARDS counters, 32 words apart
+  unsigned long long *stats;          // 12 counters (rt_stats order)
   int stack_depth, trace_zero_weight;
+  int n_packets, groups_per_tile;     // packet = group of whole pixels; n_local_tiles * groups_per_tile
+  int px_per_packet, chunks_per_packet;  // max(1, 64 / spp) pixels; ceil(spp / 64) chunks of 64 samples
+  int boxes_safe, pad3;                  // all node-box coordinates are 0 or in [2^-36, 2^59] (exact-reciprocal path)
+  int batch_div, packets_per_shard;                   // guided packet batches: left_in_shard / batch_div, clamped to [1,16]
+  long long scatter_mul;                 // ticket -> packet permutation multiplier (coprime to packets_per_shard)
 };
 
 struct LaunchCfg {
@@ -80,9 +87,9 @@ int occupancy_fma(bool prune, bool count, size_t lds_bytes);
 inline size_t lds_bytes_for(int stack_depth) {
   return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + TAG_SLOTS + 32) * 4;
 }
-inline unsigned long long scratch_floats_per_wave(int max_depth, int tile_samples) {
+inline unsigned long long scratch_floats_per_wave(int max_depth) {
   int levels = max_depth > 1 ? max_depth - 1 : 0;  // level 1 (primary) is never queued
-  return (unsigned long long)levels * QFIELDS * QCAP + 3ull * (unsigned long long)tile_samples;
+  return (unsigned long long)levels * QFIELDS * QCAP;
 }
 
 }  // namespace rtdev

@@ -3,8 +3,9 @@
 // rt_kernels_fma.hip (-ffp-contract=fast) with RT_NS set.
 //
 // Execution model (DESIGN.md has the long form):
-//   * one 64-lane wave owns one image tile (~1024 samples) at a time and pulls tile
-//     indices from a global atomic counter until none are left;
+//   * every 64-lane wave is autonomous: it pulls packets of whole pixels (<= 64 primary
+//     samples, e.g. 4 pixels of an 8x8-pixel tile at 16 spp) from sharded global counters
+//     until none are left; there is no block-level synchronisation;
 //   * lane = ray.  Primary rays are generated in registers; secondary rays
 //     (reflection / refraction, RayTracer.hs:109-156) are pushed, wave-compacted with
 //     ballot + popcount, into per-level ray queues in the wave's own HBM scratch
@@ -13,8 +14,9 @@
 //     (<= 191 rays per level);
 //   * BVH traversal (hitBVH/hits/hitsBox) keeps its per-lane stack in LDS;
 //   * recursion is flattened to weight-carrying rays: colour(sample) =
-//     sum over its rays of weight * direct colour; per-sample sums live in the wave's
-//     scratch and are resolved to the pixel average (avgColors) at tile end.
+//     sum over its rays of weight * direct colour, accumulated EXACTLY (2^-40 fixed
+//     point) in a per-pixel buffer (L2-resident), so the frame is bitwise independent of the
+//     scheduling; resolve_kernel then forms the pixel average (avgColors).
 //
 // Every arithmetic expression that decides a hit is written in the reference's
 // operand order; see the file:line notes.  Paths are relative to /root/reference.
@@ -56,17 +58,75 @@ struct Counters {
   unsigned box, sph, tri;
 };
 
+// ---- exact division by a per-ray constant ---------------------------------------------
+// hitsBox divides six box-minus-origin differences by the three direction components.
+// The divisors are fixed for a ray, so 1/d is computed ONCE per ray with a true IEEE
+// division and every quotient is then formed with Markstein's correction steps:
+//   q0 = RN(a*r);  e = a - d*q0 (exact, FMA);  q1 = RN(q0 + e*r)   -> faithful
+//   e2 = a - d*q1 (exact);                    q  = RN(q1 + e2*r)  -> RN(a/d)
+// With r = RN(1/d) and q1 within one ulp of a/d the last step returns the correctly
+// rounded quotient (Markstein 1990; Muller et al., Handbook of FP Arithmetic, Thm 4.8),
+// i.e. bit-for-bit what `/` returns -- 5 VALU ops instead of the 11-op (one of them
+// quarter-rate) IEEE division sequence.  The theorem needs no overflow/underflow
+// anywhere, which holds when
+//   |d| in [2^-40, 2^40],  origin and box coordinates are 0 or in [2^-36, 2^59]
+// (then a = c - o is 0 or a multiple of 2^-59 below 2^60, and all residuals are normal
+// numbers).  Rays or scenes outside that range take the plain-division path; +-0
+// quotients may differ in sign only, which no comparison can see.
+// tools/check_exact_div.c hammers the identity on the CPU.
+struct RayDiv {
+  float rx, ry, rz;
+  bool safe;
+};
+DEVI bool coord_safe(float c) {
+  float a = fabsf(c);
+  return c == 0.0f || (a >= 1.4551915228366852e-11f /*2^-36*/ && a <= 5.764607523034235e17f /*2^59*/);
+}
+DEVI bool dir_safe(float d) {
+  float a = fabsf(d);
+  return a >= 9.094947017729282e-13f /*2^-40*/ && a <= 1099511627776.0f /*2^40*/;
+}
+DEVI RayDiv make_raydiv(const RenderParams &P, V3 o, V3 d) {
+  RayDiv r;
+  r.rx = 1.0f / d.x;
+  r.ry = 1.0f / d.y;
+  r.rz = 1.0f / d.z;
+  r.safe = P.boxes_safe && dir_safe(d.x) && dir_safe(d.y) && dir_safe(d.z) && coord_safe(o.x) &&
+           coord_safe(o.y) && coord_safe(o.z);
+  return r;
+}
+#ifdef RT_FAST_MATH
+// FMA / fast build: plain reciprocal multiply (not bit-identical to the reference)
+DEVI float mdiv(float a, float d, float r) { (void)d; return a * r; }
+#else
+DEVI float mdiv(float a, float d, float r) {
+  float q0 = a * r;
+  float e = __builtin_fmaf(-d, q0, a);
+  float q1 = __builtin_fmaf(e, r, q0);
+  float e2 = __builtin_fmaf(-d, q1, a);
+  return __builtin_fmaf(e2, r, q1);
+}
+#endif
+
 // hitsBox (BoundingVolumeHierarchy.hs:191-204): six IEEE divisions, slab ends
 // swapped by the sign test `d >= 0`, six interval comparisons.  t0/t1 out for the
-// (result-preserving) range pruning.
-DEVI bool hits_box(V3 b, V3 d, float l, float r, float bo, float t, float n, float f, float &e0,
-                   float &e1, float &e2, float &x0, float &x1, float &x2) {
-  float tx0 = ((d.x >= 0 ? l : r) - b.x) / d.x;
-  float tx1 = ((d.x >= 0 ? r : l) - b.x) / d.x;
-  float ty0 = ((d.y >= 0 ? bo : t) - b.y) / d.y;
-  float ty1 = ((d.y >= 0 ? t : bo) - b.y) / d.y;
-  float tz0 = ((d.z >= 0 ? n : f) - b.z) / d.z;
-  float tz1 = ((d.z >= 0 ? f : n) - b.z) / d.z;
+// (result-preserving) range pruning.  SAFE selects the exact-reciprocal quotients.
+template <bool SAFE>
+DEVI bool hits_box(V3 b, V3 d, const RayDiv &rd, float l, float r, float bo, float t, float n, float f,
+                   float &e0, float &e1, float &e2, float &x0, float &x1, float &x2) {
+  float ax0 = (d.x >= 0 ? l : r) - b.x, ax1 = (d.x >= 0 ? r : l) - b.x;
+  float ay0 = (d.y >= 0 ? bo : t) - b.y, ay1 = (d.y >= 0 ? t : bo) - b.y;
+  float az0 = (d.z >= 0 ? n : f) - b.z, az1 = (d.z >= 0 ? f : n) - b.z;
+  float tx0, tx1, ty0, ty1, tz0, tz1;
+  if (SAFE) {
+    tx0 = mdiv(ax0, d.x, rd.rx); tx1 = mdiv(ax1, d.x, rd.rx);
+    ty0 = mdiv(ay0, d.y, rd.ry); ty1 = mdiv(ay1, d.y, rd.ry);
+    tz0 = mdiv(az0, d.z, rd.rz); tz1 = mdiv(az1, d.z, rd.rz);
+  } else {
+    tx0 = ax0 / d.x; tx1 = ax1 / d.x;
+    ty0 = ay0 / d.y; ty1 = ay1 / d.y;
+    tz0 = az0 / d.z; tz1 = az1 / d.z;
+  }
   e0 = tx0; e1 = ty0; e2 = tz0;
   x0 = tx1; x1 = ty1; x2 = tz1;
   return !(tx0 > ty1 || tx0 > tz1 || tx1 < ty0 || tx1 < tz0 || ty0 > tz1 || ty1 < tz0);
@@ -79,6 +139,7 @@ DEVI bool hit_sphere(V3 base, V3 dir, float4 q0, float r2, float &t_out) {
   float dirdir = dot(dir, dir);
   float ecec = dot(ec, ec);
   float discriminant = dec * dec - dirdir * (ecec - r2);
+  if (!(discriminant > 0)) { t_out = 0.0f; return false; }  // same verdict, skips sqrt + 2 divisions
   float disc_val = sqrtf(discriminant);
   V3 neg_dir = multiply(dir, -1.0f);
   float neg_dir_ec = dot(neg_dir, ec);
@@ -98,6 +159,7 @@ DEVI bool hit_triangle(V3 rb, V3 dir, float4 q0, float4 q1, float4 q2, float &t_
   V3 tn = mk(q2.y, q2.z, q2.w);
   float g = dir.x, h = dir.y, i = dir.z;
   float theta = dot(dir, tn);
+  if (theta >= 0) { t_out = 0.0f; return false; }  // back face: same verdict, skips the 3 divisions
   float j = ax - rb.x, k = ay - rb.y, l = az - rb.z;
   float ei = e * i, hf = h * f, gf = g * f, di = d * i, dh = d * h, eg = e * g;
   float ak = a * k, jb = j * b, jc = j * c, al = a * l, bl = b * l, kc = k * c;
@@ -132,19 +194,27 @@ DEVI void traverse(const RenderParams &P, unsigned *stack, int lane, bool active
   best_p = -1;
   int sp = 0;
   int cur = (active && P.has_root) ? 0 : STOP;
+  const RayDiv rd = make_raydiv(P, o, d);
+  // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
+  // denormal direction component, or an out-of-range scene)
+  const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
   while (cur != STOP) {
     if (cur >= 0) {
       const float4 *np = P.nodes + (size_t)cur * NODE_F4;
       float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
       int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
       float le0, le1, le2, lx0, lx1, lx2, re0, re1, re2, rx0, rx1, rx2;
-      bool hl = hits_box(o, d, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le0, le1, le2, lx0, lx1, lx2);
-      bool hr = false;
-      if (COUNT) cn.box += 1;
-      if (rref != REF_NONE) {
-        hr = hits_box(o, d, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re0, re1, re2, rx0, rx1, rx2);
-        if (COUNT) cn.box += 1;
+      bool hl, hr = false;
+      if (all_safe) {
+        hl = hits_box<true>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le0, le1, le2, lx0, lx1, lx2);
+        if (rref != REF_NONE)
+          hr = hits_box<true>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re0, re1, re2, rx0, rx1, rx2);
+      } else {
+        hl = hits_box<false>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le0, le1, le2, lx0, lx1, lx2);
+        if (rref != REF_NONE)
+          hr = hits_box<false>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re0, re1, re2, rx0, rx1, rx2);
       }
+      if (COUNT) cn.box += (rref != REF_NONE) ? 2 : 1;
       bool left_first = true;
       if (PRUNE) {
         float lim = prune_limit(best_t);
@@ -259,295 +329,398 @@ DEVI int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
+#endif
+
+// Exact, order-independent accumulation: a contribution is converted to 2^-40 fixed
+// point (int64); integer addition is associative, so a pixel's sum does not depend
+// on the order in which the scheduler happens to process its rays (bitwise
+// reproducible frames, identical for every tile partition).  Range +-2^23; a
+// non-finite contribution (the reference can produce k = +inf, RayTracer.hs:141)
+// saturates to +-2^22 and is therefore still clamped to 0 / 1 by writePPM.
+DEVI long long to_fixed(float c) {
+  c = fminf(fmaxf(c, -4194304.0f), 4194304.0f);
+  return (long long)(c * 1099511627776.0f);
+}
+
+// Packet fetch.  PACKET_SHARDS ticket counters (one 128-B line each); ticket i of shard
+// sh is packet (i * M mod per_shard) * PACKET_SHARDS + sh.  A wave takes a BATCH of ids per atomic (one L2
+// round trip per batch instead of per 64 rays); the batch shrinks towards the end of
+// the shard ("guided" scheduling) so the tail stays one packet long.
+struct PacketSrc {
+  int next, end, shard;   // ids next .. end-1 of `shard` are owned by this wave
+  int tries;              // shards found exhausted so far
+};
+DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
+  const int per_shard = P.packets_per_shard;
+  while (ps.tries < PACKET_SHARDS) {
+    while (ps.next < ps.end) {
+      // scatter: consecutive tickets of a shard map to packets far apart in the frame
+      // (i -> i * M mod per_shard, M coprime to per_shard), so a batch does not sit in
+      // one expensive region (glass costs ~100x a floor packet)
+      long long j = ((long long)ps.next * P.scatter_mul) % per_shard;
+      ++ps.next;
+      long long id = j * PACKET_SHARDS + ps.shard;
+      if (id < (long long)P.n_packets) return (int)id;
+    }
+    int got = 0, want = 0;
+    if (lane == 0) {
+      // estimate of what is left from the last ticket we saw; first call: everything
+      int left = per_shard - ps.end;
+      want = left / P.batch_div;
+      want = want < 1 ? 1 : (want > 16 ? 16 : want);
+      got = (int)atomicAdd(P.tile_counter + ps.shard * 32, (unsigned)want);
+    }
+    got = wave_uniform(got);
+    want = wave_uniform(want);
+    if (got < per_shard) {
+      ps.next = got;
+      ps.end = got + want < per_shard ? got + want : per_shard;
+    } else {  // shard exhausted: move on to the next one
+      ++ps.tries;
+      ps.shard = (ps.shard + 1) % PACKET_SHARDS;
+      ps.next = ps.end = 0;
+    }
+  }
+  return -1;
+}
+
 template <bool PRUNE, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(const RenderParams P) {
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
   extern __shared__ unsigned lds[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WAVES_PER_BLOCK + wib;
   unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
-  unsigned *tag = stack + P.stack_depth * 64;
-  unsigned *cnt = tag + TAG_SLOTS;  // cnt[L], L = 2..max_depth : rays queued at level L
+  // volatile: lanes of one wave race on tag[] on purpose; the read-back must really
+  // come from LDS (no store-to-load forwarding inside a lane)
+  volatile unsigned *tag = stack + P.stack_depth * 64;
+  unsigned *cnt = stack + P.stack_depth * 64 + TAG_SLOTS;  // cnt[L], L = 2..max_depth : rays queued at level L
 
   float *Q = P.scratch + gwave * P.scratch_stride;
-  const int n_qlevels = P.max_depth > 1 ? P.max_depth - 1 : 0;
-  float *acc = Q + (size_t)n_qlevels * QFIELDS * QCAP;  // [3][tile_samples]
-  const int TS = P.tile_samples;
+  long long *acc = P.acc;  // [n_local_pixels][3] fixed point
   const int tile_px = P.tile_w * P.tile_h;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   unsigned long long n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
   Counters cn = {0, 0, 0};
+  const unsigned long long wave_t0 = wall_clock64();
+
+  if (lane < 32) cnt[lane] = 0u;
+  bool more_packets = P.max_depth >= 1;
+  int cur_packet = -1, cur_chunk = 0;  // a packet = whole pixels; spp > 64 needs several chunks
+  PacketSrc psrc = {0, 0, (int)(gwave % PACKET_SHARDS), 0};
 
   for (;;) {
-    // ---- fetch a tile -------------------------------------------------------
-    int ltile = 0;
-    if (lane == 0) ltile = (int)atomicAdd(P.tile_counter, 1u);
-    ltile = wave_uniform(ltile);
-    if (ltile >= P.n_local_tiles) break;
-    const int gtile = P.rank + ltile * P.nranks;
-    const int tx0 = (gtile % P.tiles_x) * P.tile_w;
-    const int ty0 = (gtile / P.tiles_x) * P.tile_h;
-
-    for (int q = lane; q < 3 * TS; q += 64) acc[q] = 0.0f;
-    for (int q = lane; q < TAG_SLOTS; q += 64) tag[q] = 0u;
-    if (lane < 32) cnt[lane] = 0u;
-    unsigned epoch = 0;
-    int next_sample = 0;
-
-    for (;;) {
-      __threadfence_block();  // own-wave queue/acc stores -> visible to the loads below
-      // ---- choose the level to run: deepest full queue, else new primaries, else
-      //      deepest non-empty queue --------------------------------------------
-      int level = 0;
-      for (int L = P.max_depth; L >= 2; --L)
-        if ((int)cnt[L] >= 64) { level = L; break; }
-      if (level == 0) {
-        if (next_sample < TS && P.max_depth >= 1) level = 1;
-        else
-          for (int L = P.max_depth; L >= 2; --L)
-            if ((int)cnt[L] > 0) { level = L; break; }
+    __threadfence_block();  // this wave's queue / accumulator stores -> visible to its loads
+    // ---- choose what to run: deepest full queue, else the next chunk of primaries,
+    //      else the deepest non-empty queue -------------------------------------------
+    int level = 0;
+    for (int L = P.max_depth; L >= 2; --L)
+      if ((int)cnt[L] >= 64) { level = L; break; }
+    if (level == 0) {
+      if (cur_packet < 0 && more_packets) {
+        cur_packet = fetch_packet(P, lane, psrc);
+        cur_chunk = 0;
+        if (cur_packet < 0) more_packets = false;
       }
-      level = wave_uniform(level);
-      if (level == 0) break;
+      if (cur_packet >= 0) level = 1;
+      else
+        for (int L = P.max_depth; L >= 2; --L)
+          if ((int)cnt[L] > 0) { level = L; break; }
+    }
+    level = wave_uniform(level);
+    if (level == 0) break;
 
-      // ---- obtain 64 (or fewer) rays ---------------------------------------------
-      bool active;
-      V3 o, d, W;
-      float s0, s1;
-      unsigned slot;
-      if (level == 1) {
-        int q = next_sample + lane;
-        next_sample += 64;
-        int pit = q / P.spp, s = q - pit * P.spp;
-        int px = tx0 + pit % P.tile_w, py = ty0 + pit / P.tile_w;
-        active = (q < TS) && (px < P.W) && (py < P.H);
-        slot = (unsigned)q;
-        W = mk(1.0f, 1.0f, 1.0f);
-        o = mk(0, 0, 0); d = mk(0, 0, 1); s0 = 0; s1 = 0;
-        if (active) {
-          // render (RayTracer.hs:18-23): list position k uses grid k mod n_grids
-          size_t kpix = (size_t)py * P.W + px;
-          const float *F = P.f6 + ((kpix % (size_t)P.n_grids) * (size_t)P.spp + s) * 6;
-          float fi = (float)px, fj = (float)(P.H - 1 - py);
-          get_ray(P, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
-          s0 = F[4];
-          s1 = F[5];
-        }
-        n_primary += __popcll(__ballot(active));
+    // ---- obtain 64 (or fewer) rays -------------------------------------------------
+    bool active;
+    bool first_touch = false;  // level 1, first chunk of its pixels: store, do not add
+    V3 o, d, W;
+    float s0, s1;
+    unsigned pix;  // local pixel index: ltile * tile_px + (pixel in tile)
+    int px = 0, py = 0, smp = 0;
+    if (level == 1) {
+      const int ltile = cur_packet / P.groups_per_tile, grp = cur_packet - ltile * P.groups_per_tile;
+      const int gtile = P.rank + ltile * P.nranks;
+      const int tx0 = (gtile % P.tiles_x) * P.tile_w;
+      const int ty0 = (gtile / P.tiles_x) * P.tile_h;
+      int pit;
+      bool in_packet;
+      if (P.spp <= 64) {
+        int sub = lane / P.spp;
+        smp = lane - sub * P.spp;
+        pit = grp * P.px_per_packet + sub;
+        in_packet = sub < P.px_per_packet;
       } else {
-        int have = (int)cnt[level];
-        int take = have < 64 ? have : 64;
-        int idx = have - take + lane;
-        active = lane < take;
-        const float *ql = Q + (size_t)(level - 2) * QFIELDS * QCAP;
-        o = mk(0, 0, 0); d = mk(0, 0, 1); W = mk(0, 0, 0); s0 = 0; s1 = 0; slot = 0;
-        if (active) {
-          o = mk(ql[0 * QCAP + idx], ql[1 * QCAP + idx], ql[2 * QCAP + idx]);
-          d = mk(ql[3 * QCAP + idx], ql[4 * QCAP + idx], ql[5 * QCAP + idx]);
-          W = mk(ql[6 * QCAP + idx], ql[7 * QCAP + idx], ql[8 * QCAP + idx]);
-          s0 = ql[9 * QCAP + idx];
-          s1 = ql[10 * QCAP + idx];
-          slot = __float_as_uint(ql[11 * QCAP + idx]);
-        }
-        if (lane == 0) cnt[level] = (unsigned)(have - take);
-        unsigned long long am = __ballot(active);
-        unsigned long long rm = __ballot(active && (slot & SLOT_REFRACTION));
-        n_refr += __popcll(rm);
-        n_refl += __popcll(am) - __popcll(rm);
-        slot &= ~SLOT_REFRACTION;
+        smp = cur_chunk * 64 + lane;
+        pit = grp;
+        in_packet = smp < P.spp;
       }
+      first_touch = cur_chunk == 0;
+      if (++cur_chunk >= P.chunks_per_packet) cur_packet = -1;
+      px = tx0 + pit % P.tile_w;
+      py = ty0 + pit / P.tile_w;
+      active = in_packet && (pit < tile_px) && (px < P.W) && (py < P.H);
+      pix = (unsigned)(ltile * tile_px + pit);
+      W = mk(1.0f, 1.0f, 1.0f);
+      o = mk(0, 0, 0); d = mk(0, 0, 1); s0 = 0; s1 = 0;
+      if (active) {
+        // render (RayTracer.hs:18-23): list position k uses grid k mod n_grids
+        size_t kpix = (size_t)py * P.W + px;
+        const float *F = P.f6 + ((kpix % (size_t)P.n_grids) * (size_t)P.spp + smp) * 6;
+        float fi = (float)px, fj = (float)(P.H - 1 - py);
+        get_ray(P, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
+        s0 = F[4];
+        s1 = F[5];
+      }
+      n_primary += __popcll(__ballot(active));
+    } else {
+      int have = (int)cnt[level];
+      int take = have < 64 ? have : 64;
+      int idx = have - take + lane;
+      active = lane < take;
+      const float *ql = Q + (size_t)(level - 2) * QFIELDS * QCAP;
+      o = mk(0, 0, 0); d = mk(0, 0, 1); W = mk(0, 0, 0); s0 = 0; s1 = 0; pix = 0;
+      if (active) {
+        o = mk(ql[0 * QCAP + idx], ql[1 * QCAP + idx], ql[2 * QCAP + idx]);
+        d = mk(ql[3 * QCAP + idx], ql[4 * QCAP + idx], ql[5 * QCAP + idx]);
+        W = mk(ql[6 * QCAP + idx], ql[7 * QCAP + idx], ql[8 * QCAP + idx]);
+        s0 = ql[9 * QCAP + idx];
+        s1 = ql[10 * QCAP + idx];
+        pix = __float_as_uint(ql[11 * QCAP + idx]);
+      }
+      if (lane == 0) cnt[level] = (unsigned)(have - take);
+      unsigned long long am = __ballot(active);
+      unsigned long long rm = __ballot(active && (pix & SLOT_REFRACTION));
+      n_refr += __popcll(rm);
+      n_refl += __popcll(am) - __popcll(rm);
+      pix &= ~SLOT_REFRACTION;
+    }
 
-      // ---- raytrace (RayTracer.hs:55-71): closest hit ------------------------------
-      float t;
-      int p;
-      traverse<false, PRUNE, COUNT>(P, stack, lane, active, o, d, 0.0f, t, p, cn);
-      const bool hit = active && p >= 0;
-      n_hits += __popcll(__ballot(hit));
+    // ---- raytrace (RayTracer.hs:55-71): closest hit ----------------------------------
+    float t;
+    int p;
+    traverse<false, PRUNE, COUNT>(P, stack, lane, active, o, d, 0.0f, t, p, cn);
+    const bool hit = active && p >= 0;
+    n_hits += __popcll(__ballot(hit));
 
-      if (level == 1) {
-        n_phits += __popcll(__ballot(hit));
-        if (P.hit_ids && active) {
-          int q = (int)slot;
-          int pit = q / P.spp, s = q - pit * P.spp;
-          int px = tx0 + pit % P.tile_w, py = ty0 + pit / P.tile_w;
-          uint32_t id = RT_HIT_NONE;
-          if (hit) id = (uint32_t)__float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].z);
-          P.hit_ids[((size_t)py * P.W + px) * P.spp + s] = id;
+    if (level == 1) {
+      n_phits += __popcll(__ballot(hit));
+      if (P.hit_ids && active) {
+        uint32_t id = RT_HIT_NONE;
+        if (hit) id = (uint32_t)__float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].z);
+        P.hit_ids[((size_t)py * P.W + px) * P.spp + smp] = id;
+      }
+    }
+
+    // ---- shade -----------------------------------------------------------------------
+    V3 pt = mk(0, 0, 0), n = mk(0, 1, 0), clr = mk(0, 0, 0);
+    int mat = 0;
+    if (hit) {
+      const float4 *q = P.prims + (size_t)p * PRIM_F4;
+      float4 q3 = q[3];
+      mat = __float_as_int(q3.y);
+      pt = add(o, multiply(d, t));  // :63
+      if (__float_as_int(q3.x) != 0) {
+        float4 q2 = q[2];
+        n = mk(q2.y, q2.z, q2.w);   // getNormal, triangle (:77)
+      } else {
+        float4 q0 = q[0];
+        n = divide(subt(pt, mk(q0.x, q0.y, q0.z)), q0.w);  // getNormal, sphere (:76)
+      }
+    }
+    const float *M = P.materials + (size_t)mat * 12;
+    const V3 v = mk(-d.x, -d.y, -d.z);  // :65
+
+    // getDirectColor (:81-106).  The reference folds the light list from the right:
+    // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
+    // exactly that order.
+    if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
+    for (int li = P.n_lights - 1; li >= 0; --li) {
+      const float *Lp = P.lights + (size_t)li * 12;
+      V3 l_a = ld3(Lp + 3), l_b = ld3(Lp + 6);
+      V3 l_pt = add(ld3(Lp + 0), add(mk(l_a.x * s0, l_a.y * s0, l_a.z * s0),
+                                     mk(l_b.x * s1, l_b.y * s1, l_b.z * s1)));  // :96
+      V3 l = subt(l_pt, pt);
+      V3 l_dir = normalize(l);
+      float max_d = magnitude(l);
+      float st;
+      int sprim;
+      traverse<true, PRUNE, COUNT>(P, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      n_shadow += __popcll(__ballot(hit));
+      if (hit && sprim < 0) {
+        V3 l_c = ld3(Lp + 9);
+        float s = hs_max(0.0f, dot(l_dir, n));
+        V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
+        V3 h = normalize(add(v, l_dir));
+        float pw = powf(hs_max(0.0f, dot(n, h)), M[6]);
+        V3 spec_c = cscale(cmul(l_c, ld3(M + 3)), pw);
+        clr = add(add(diffuse_c, spec_c), clr);
+      }
+    }
+
+    // ---- accumulate weight * direct colour into the PIXEL -----------------------------
+    // All rays of a pixel live in this wave (packets hold whole pixels), so a plain
+    // read-modify-write of the pixel's fixed-point sums is race-free across waves.
+    // Inside the chunk, lanes of one pixel are first summed with a segmented wave scan
+    // over contiguous runs; the last lane of each run owns the update.  Runs of the
+    // same pixel that are not adjacent (rare) take turns through the LDS tag table.
+    {
+      V3 c = cmul(W, clr);
+      const bool contrib = (level == 1) ? active : hit;
+      long long cr = contrib ? to_fixed(c.x) : 0, cg = contrib ? to_fixed(c.y) : 0,
+                cb = contrib ? to_fixed(c.z) : 0;
+      const unsigned key = contrib ? pix : (0xC0000000u | (unsigned)lane);  // unique when idle
+      const unsigned key_prev = __shfl_up(key, 1);
+      const unsigned key_next = __shfl_down(key, 1);
+      const bool head = (lane == 0) || key_prev != key;
+      const bool tail = contrib && ((lane == 63) || key_next != key);
+      const unsigned long long heads = __ballot(head);
+      if (~heads) {  // some run is longer than one lane
+        const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        const int start = 63 - __clzll(upto);  // first lane of this lane's run
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          long long ur = __shfl_up(cr, dlt), ug = __shfl_up(cg, dlt), ub = __shfl_up(cb, dlt);
+          if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
         }
       }
-
-      // ---- shade -------------------------------------------------------------------
-      V3 pt = mk(0, 0, 0), n = mk(0, 1, 0), clr = mk(0, 0, 0);
-      int mat = 0;
-      if (hit) {
-        const float4 *q = P.prims + (size_t)p * PRIM_F4;
-        float4 q3 = q[3];
-        mat = __float_as_int(q3.y);
-        pt = add(o, multiply(d, t));  // :63
-        if (__float_as_int(q3.x) != 0) {
-          float4 q2 = q[2];
-          n = mk(q2.y, q2.z, q2.w);   // getNormal, triangle (:77)
-        } else {
-          float4 q0 = q[0];
-          n = divide(subt(pt, mk(q0.x, q0.y, q0.z)), q0.w);  // getNormal, sphere (:76)
-        }
-      }
-      const float *M = P.materials + (size_t)mat * 12;
-      const V3 v = mk(-d.x, -d.y, -d.z);  // :65
-
-      // getDirectColor (:81-106).  The reference folds the light list from the right:
-      // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
-      // exactly that order.
-      if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
-      for (int li = P.n_lights - 1; li >= 0; --li) {
-        const float *Lp = P.lights + (size_t)li * 12;
-        V3 l_a = ld3(Lp + 3), l_b = ld3(Lp + 6);
-        V3 l_pt = add(ld3(Lp + 0), add(mk(l_a.x * s0, l_a.y * s0, l_a.z * s0),
-                                       mk(l_b.x * s1, l_b.y * s1, l_b.z * s1)));  // :96
-        V3 l = subt(l_pt, pt);
-        V3 l_dir = normalize(l);
-        float max_d = magnitude(l);
-        float st;
-        int sprim;
-        traverse<true, PRUNE, COUNT>(P, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
-        n_shadow += __popcll(__ballot(hit));
-        if (hit && sprim < 0) {
-          V3 l_c = ld3(Lp + 9);
-          float s = hs_max(0.0f, dot(l_dir, n));
-          V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
-          V3 h = normalize(add(v, l_dir));
-          float pw = powf(hs_max(0.0f, dot(n, h)), M[6]);
-          V3 spec_c = cscale(cmul(l_c, ld3(M + 3)), pw);
-          clr = add(add(diffuse_c, spec_c), clr);
-        }
-      }
-
-      // ---- accumulate weight * direct colour into the sample (conflict-free) -------
-      {
-        V3 c = cmul(W, clr);
-        bool pending = hit;
-        const unsigned h = (slot * 0x9E3779B1u) >> 24;  // TAG_SLOTS = 256
+      long long *a = acc + (size_t)pix * 3;
+      if (level == 1 && first_touch) {
+        // first (only, for spp <= 64) chunk of these pixels: plain store, which also
+        // writes the zero of an all-miss pixel, so the buffer needs no clearing
+        if (tail) { a[0] = cr; a[1] = cg; a[2] = cb; }
+      } else {
+        bool pending = tail;
+        const unsigned h = (pix * 0x9E3779B1u) >> 24;  // TAG_SLOTS = 256
         while (__ballot(pending)) {
-          ++epoch;
-          unsigned key = (epoch << 6) | (unsigned)(63 - lane);
-          if (pending) atomicMax(&tag[h], key);
-          bool win = pending && tag[h] == key;
+          if (pending) tag[h] = (unsigned)lane;
+          bool win = pending && tag[h] == (unsigned)lane;
           if (win) {
-            acc[0 * TS + slot] += c.x;
-            acc[1 * TS + slot] += c.y;
-            acc[2 * TS + slot] += c.z;
+            a[0] += cr; a[1] += cg; a[2] += cb;
             pending = false;
           }
           if (__ballot(pending)) __threadfence_block();
         }
       }
-
-      // ---- getIndirectColor (:109-156): emit the child rays -----------------------
-      if (level < P.max_depth) {
-        bool e_refl = false, e_refr = false;
-        V3 refl_v = mk(0, 0, 1), tdir = mk(0, 0, 1), w_refl = mk(0, 0, 0), w_refr = mk(0, 0, 0);
-        if (hit) {
-          V3 spec = ld3(M + 3);
-          float phong = M[6], reflx = M[7], nt = M[8];
-          V3 refl0 = reflect(d, n);
-          V3 ou, ov;
-          orthonormal(refl0, ou, ov);
-          float a = 1 / phong;
-          float ju = -(a / 2) + s0 * a;
-          float jv = -(a / 2) + s1 * a;
-          refl_v = add(refl0, add(multiply(ou, ju), multiply(ov, jv)));
-          V3 f_refl = cscale(spec, reflx);
-          e_refl = true;
-          if (nt != 0) {
-            V3 k = mk(1, 1, 1);
-            float c;
-            bool has_t;
-            float dn = dot(d, n);
-            if (dn < 0) {
-              c = -dn;
-              has_t = refract(d, n, nt, tdir);
-            } else {
-              has_t = refract(d, multiply(n, -1), 1 / nt, tdir);
-              k = mk(expf(-M[9]), expf(-M[10]), expf(-M[11]));
-              c = has_t ? dot(tdir, n) : 0.0f;
-            }
-            float r_0 = (nt - 1) * (nt - 1) / ((nt + 1) * (nt + 1));
-            float om = 1 - c;
-            float bigR = r_0 + (1 - r_0) * (om * om * om * om * om);
-            if (has_t) {
-              f_refl = cmul(cscale(f_refl, bigR), k);
-              w_refr = cmul(W, cscale(k, 1 - bigR));
-              e_refr = true;
-            } else {
-              f_refl = cmul(f_refl, k);
-            }
-          }
-          w_refl = cmul(W, f_refl);
-          if (!P.trace_zero_weight) {
-            if (w_refl.x == 0 && w_refl.y == 0 && w_refl.z == 0) e_refl = false;
-            if (e_refr && w_refr.x == 0 && w_refr.y == 0 && w_refr.z == 0) e_refr = false;
-          }
-        }
-        unsigned long long m1 = __ballot(e_refl), m2 = __ballot(e_refr);
-        if (m1 | m2) {
-          const int nl = level + 1;
-          int base = (int)cnt[nl];
-          int off = base + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask);
-          float *qn = Q + (size_t)(nl - 2) * QFIELDS * QCAP;
-          if (e_refl) {
-            qn[0 * QCAP + off] = pt.x; qn[1 * QCAP + off] = pt.y; qn[2 * QCAP + off] = pt.z;
-            qn[3 * QCAP + off] = refl_v.x; qn[4 * QCAP + off] = refl_v.y; qn[5 * QCAP + off] = refl_v.z;
-            qn[6 * QCAP + off] = w_refl.x; qn[7 * QCAP + off] = w_refl.y; qn[8 * QCAP + off] = w_refl.z;
-            qn[9 * QCAP + off] = s0; qn[10 * QCAP + off] = s1;
-            qn[11 * QCAP + off] = __uint_as_float(slot);
-            ++off;
-          }
-          if (e_refr) {
-            qn[0 * QCAP + off] = pt.x; qn[1 * QCAP + off] = pt.y; qn[2 * QCAP + off] = pt.z;
-            qn[3 * QCAP + off] = tdir.x; qn[4 * QCAP + off] = tdir.y; qn[5 * QCAP + off] = tdir.z;
-            qn[6 * QCAP + off] = w_refr.x; qn[7 * QCAP + off] = w_refr.y; qn[8 * QCAP + off] = w_refr.z;
-            qn[9 * QCAP + off] = s0; qn[10 * QCAP + off] = s1;
-            qn[11 * QCAP + off] = __uint_as_float(slot | SLOT_REFRACTION);
-          }
-          if (lane == 0) cnt[nl] = (unsigned)(base + __popcll(m1) + __popcll(m2));
-        }
-      }
-    }  // level loop
-
-    // ---- avgColors (Surfaces.hs:15-18): left fold from 0, then divide by n --------
-    __threadfence_block();
-    for (int pit = lane; pit < tile_px; pit += 64) {
-      int px = tx0 + pit % P.tile_w, py = ty0 + pit / P.tile_w;
-      if (px >= P.W || py >= P.H) continue;
-      float r = 0.0f, g = 0.0f, b = 0.0f;
-      for (int s = 0; s < P.spp; ++s) {
-        int q = pit * P.spp + s;
-        r = r + acc[0 * TS + q];
-        g = g + acc[1 * TS + q];
-        b = b + acc[2 * TS + q];
-      }
-      float nf = (float)P.spp;
-      size_t o3 = P.compact ? ((size_t)ltile * tile_px + pit) * 3 : ((size_t)py * P.W + px) * 3;
-      P.rgb[o3 + 0] = r / nf;
-      P.rgb[o3 + 1] = g / nf;
-      P.rgb[o3 + 2] = b / nf;
     }
-  }  // tile loop
 
-  // ---- statistics ------------------------------------------------------------------
+    // ---- getIndirectColor (:109-156): emit the child rays -----------------------------
+    if (level < P.max_depth) {
+      bool e_refl = false, e_refr = false;
+      V3 refl_v = mk(0, 0, 1), tdir = mk(0, 0, 1), w_refl = mk(0, 0, 0), w_refr = mk(0, 0, 0);
+      if (hit) {
+        V3 spec = ld3(M + 3);
+        float phong = M[6], reflx = M[7], nt = M[8];
+        V3 refl0 = reflect(d, n);
+        V3 ou, ov;
+        orthonormal(refl0, ou, ov);
+        float a = 1 / phong;
+        float ju = -(a / 2) + s0 * a;
+        float jv = -(a / 2) + s1 * a;
+        refl_v = add(refl0, add(multiply(ou, ju), multiply(ov, jv)));
+        V3 f_refl = cscale(spec, reflx);
+        e_refl = true;
+        if (nt != 0) {
+          V3 k = mk(1, 1, 1);
+          float c;
+          bool has_t;
+          float dn = dot(d, n);
+          if (dn < 0) {
+            c = -dn;
+            has_t = refract(d, n, nt, tdir);
+          } else {
+            has_t = refract(d, multiply(n, -1), 1 / nt, tdir);
+            k = mk(expf(-M[9]), expf(-M[10]), expf(-M[11]));
+            c = has_t ? dot(tdir, n) : 0.0f;
+          }
+          float r_0 = (nt - 1) * (nt - 1) / ((nt + 1) * (nt + 1));
+          float om = 1 - c;
+          float bigR = r_0 + (1 - r_0) * (om * om * om * om * om);
+          if (has_t) {
+            f_refl = cmul(cscale(f_refl, bigR), k);
+            w_refr = cmul(W, cscale(k, 1 - bigR));
+            e_refr = true;
+          } else {
+            f_refl = cmul(f_refl, k);
+          }
+        }
+        w_refl = cmul(W, f_refl);
+        if (!P.trace_zero_weight) {
+          if (w_refl.x == 0 && w_refl.y == 0 && w_refl.z == 0) e_refl = false;
+          if (e_refr && w_refr.x == 0 && w_refr.y == 0 && w_refr.z == 0) e_refr = false;
+        }
+      }
+      unsigned long long m1 = __ballot(e_refl), m2 = __ballot(e_refr);
+      if (m1 | m2) {
+        const int nl = level + 1;
+        int base = (int)cnt[nl];
+        int off = base + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask);
+        float *qn = Q + (size_t)(nl - 2) * QFIELDS * QCAP;
+        if (e_refl) {
+          qn[0 * QCAP + off] = pt.x; qn[1 * QCAP + off] = pt.y; qn[2 * QCAP + off] = pt.z;
+          qn[3 * QCAP + off] = refl_v.x; qn[4 * QCAP + off] = refl_v.y; qn[5 * QCAP + off] = refl_v.z;
+          qn[6 * QCAP + off] = w_refl.x; qn[7 * QCAP + off] = w_refl.y; qn[8 * QCAP + off] = w_refl.z;
+          qn[9 * QCAP + off] = s0; qn[10 * QCAP + off] = s1;
+          qn[11 * QCAP + off] = __uint_as_float(pix);
+          ++off;
+        }
+        if (e_refr) {
+          qn[0 * QCAP + off] = pt.x; qn[1 * QCAP + off] = pt.y; qn[2 * QCAP + off] = pt.z;
+          qn[3 * QCAP + off] = tdir.x; qn[4 * QCAP + off] = tdir.y; qn[5 * QCAP + off] = tdir.z;
+          qn[6 * QCAP + off] = w_refr.x; qn[7 * QCAP + off] = w_refr.y; qn[8 * QCAP + off] = w_refr.z;
+          qn[9 * QCAP + off] = s0; qn[10 * QCAP + off] = s1;
+          qn[11 * QCAP + off] = __uint_as_float(pix | SLOT_REFRACTION);
+        }
+        if (lane == 0) cnt[nl] = (unsigned)(base + __popcll(m1) + __popcll(m2));
+      }
+    }
+  }  // scheduling loop
+
+  // ---- statistics --------------------------------------------------------------------
   if (lane == 0) {
+    unsigned long long life = wall_clock64() - wave_t0;  // 100 MHz ticks (diagnostics)
     atomicAdd(&P.stats[0], n_primary);
     atomicAdd(&P.stats[1], n_shadow);
     atomicAdd(&P.stats[2], n_refl);
     atomicAdd(&P.stats[3], n_refr);
     atomicAdd(&P.stats[7], n_phits);
     atomicAdd(&P.stats[8], n_hits);
+    atomicAdd(&P.stats[9], life);
+    atomicMax(&P.stats[10], life);
+    atomicAdd(&P.stats[11], 1ull);
   }
   if (COUNT) {
     atomicAdd(&P.stats[4], (unsigned long long)cn.box);
     atomicAdd(&P.stats[5], (unsigned long long)cn.sph);
     atomicAdd(&P.stats[6], (unsigned long long)cn.tri);
+  }
+}
+
+// avgColors (Surfaces.hs:15-18) per pixel: sum of the sample colours divided by the
+// count.  One thread per local pixel; the sum is the exact fixed-point total rounded
+// once to fp32 (the reference rounds after every addition: <= a few ulp apart).
+__global__ void resolve_kernel(const RenderParams P) {
+  const int tile_px = P.tile_w * P.tile_h;
+  const size_t total = (size_t)P.n_local_tiles * tile_px;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int ltile = (int)(i / tile_px), pit = (int)(i % tile_px);
+    int gtile = P.rank + ltile * P.nranks;
+    int px = (gtile % P.tiles_x) * P.tile_w + pit % P.tile_w;
+    int py = (gtile / P.tiles_x) * P.tile_h + pit / P.tile_w;
+    if (px >= P.W || py >= P.H) continue;
+    // exact sum of all the pixel's contributions, rounded once to fp32
+    const long long *a = P.acc + i * 3;
+    float r = (float)((double)a[0] * 9.094947017729282e-13);  // 2^-40
+    float g = (float)((double)a[1] * 9.094947017729282e-13);
+    float b = (float)((double)a[2] * 9.094947017729282e-13);
+    float nf = (float)P.spp;
+    size_t o3 = P.compact ? i * 3 : ((size_t)py * P.W + px) * 3;
+    P.rgb[o3 + 0] = r / nf;
+    P.rgb[o3 + 1] = g / nf;
+    P.rgb[o3 + 2] = b / nf;
   }
 }
 
@@ -564,6 +737,12 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   } else {
     if (cfg.count) launch_t<false, true>(p, cfg, s);
     else launch_t<false, false>(p, cfg, s);
+  }
+  size_t total = (size_t)p.n_local_tiles * p.tile_w * p.tile_h;
+  if (total) {
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, s, p);
   }
 }
 

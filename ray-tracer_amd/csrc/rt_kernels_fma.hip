@@ -2,6 +2,7 @@
 // -ffp-contract=fast, so the Geometry3 vector math contracts to v_fma_f32
 // (BASELINE.json north_star).  Selected with RT_FLAG_FMA.
 #define RT_NS fma
+#define RT_FAST_MATH 1  // slab quotients by reciprocal multiply
 #include "rt_kernels.inl"
 
 namespace rtdev {

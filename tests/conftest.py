@@ -26,7 +26,7 @@ def oracle():
 
 
 def make_world(rt, name, width, height, rays_per_pixel, bvh="sah", depth=None, view=None, lens=None):
-    cfg = rt.default_config(name if not name.startswith("mesh:") else "bench6")
+    cfg = rt.default_config(name if not name.startswith("mesh:") else "mesh")
     cfg.image_width, cfg.image_height = width, height
     cfg.anti_aliasing = rays_per_pixel
     if depth is not None:

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Per-tile / per-wave time diagnostics of one frame (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import rt_amd as rt
+for wl in sys.argv[1:] or ["c2"]:
+    world = bench.make_world(wl)
+    grids = rt.generate_grids(bench.SEED, world.width + 10, world.camera.aa)
+    r = rt.Renderer(0)
+    r.set_world(world); r.set_samples(grids)
+    for i in range(3):
+        rgb, _, st = r.render(0)
+    til = r.tiling()
+    print(wl, f"kernel {st.ms_kernel:.3f} ms  tiles {til.n_tiles} ({til.tile_w}x{til.tile_h})  "
+          f"waves {st.n_waves}  wave avg {st.wave_ticks_sum/max(1,st.n_waves)/100:.1f} us  "
+          f"wave max {st.wave_ticks_max/100:.1f} us "
+          f"rays {st.rays_total}")
+    r.close()
