@@ -46,6 +46,10 @@ struct rt_ctx {
   unsigned long long *d_stats = nullptr;
   long long *d_acc = nullptr;
   size_t acc_samples = 0;
+  unsigned char *d_pclass = nullptr;
+  unsigned *d_block_hist = nullptr;
+  int *d_order = nullptr;
+  size_t order_cap = 0;
   // staging for the host-pointer form
   float *d_rgb = nullptr;
   size_t d_rgb_floats = 0;
@@ -257,6 +261,23 @@ int prepare(rt_ctx *c, uint32_t flags) {
     c->scratch_floats = need;
   }
   c->scratch_waves = waves;
+  {
+    int ppp = std::max(1, 64 / c->spp);
+    size_t n_packets = (size_t)c->tiling.n_local_tiles *
+                       ((size_t)(c->tiling.tile_w * c->tiling.tile_h + ppp - 1) / ppp);
+    if (n_packets > c->order_cap || !c->d_order) {
+      if (c->d_order) (void)hipFree(c->d_order);
+      if (c->d_pclass) (void)hipFree(c->d_pclass);
+      c->d_order = nullptr;
+      c->d_pclass = nullptr;
+      c->order_cap = 0;
+      size_t cap = std::max<size_t>(n_packets, 256);
+      HIP_TRY(c, hipMalloc((void **)&c->d_order, cap * sizeof(int)));
+      HIP_TRY(c, hipMalloc((void **)&c->d_pclass, cap));
+      c->order_cap = cap;
+    }
+    if (!c->d_block_hist) HIP_TRY(c, hipMalloc((void **)&c->d_block_hist, (1024 * 4 + 64) * sizeof(unsigned)));
+  }
   c->prepared = true;
   return RT_OK;
 }
@@ -330,13 +351,12 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
 
   p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
-  {
-    auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
-    long long n = std::max(1, p.packets_per_shard);
-    long long m = std::max<long long>(1, (long long)(0.6180339887 * (double)n));
-    while (gcd(m, n) != 1) ++m;
-    p.scatter_mul = m % n ? m % n : 1;
-  }
+  p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
+  p.probe_blocks = std::max(1, (p.n_packets + p.probe_span - 1) / p.probe_span);
+  p.pclass = c->d_pclass;
+  p.block_hist = c->d_block_hist;
+  p.class_totals = c->d_block_hist + 1024 * 4;
+  p.order = c->d_order;
   HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
   HIP_TRY(c, hipEventRecord(c->ev0, s));
@@ -411,7 +431,8 @@ void rt_shutdown(rt_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
-                  c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc};
+                  c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
+                  c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

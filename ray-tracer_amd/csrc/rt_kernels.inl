@@ -345,7 +345,7 @@ DEVI long long to_fixed(float c) {
 }
 
 // Packet fetch.  PACKET_SHARDS ticket counters (one 128-B line each); ticket i of shard
-// sh is packet (i * M mod per_shard) * PACKET_SHARDS + sh.  A wave takes a BATCH of ids per atomic (one L2
+// sh is entry i * PACKET_SHARDS + sh of the cost-sorted packet order.  A wave takes a BATCH of ids per atomic (one L2
 // round trip per batch instead of per 64 rays); the batch shrinks towards the end of
 // the shard ("guided" scheduling) so the tail stays one packet long.
 struct PacketSrc {
@@ -356,20 +356,24 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
   const int per_shard = P.packets_per_shard;
   while (ps.tries < PACKET_SHARDS) {
     while (ps.next < ps.end) {
-      // scatter: consecutive tickets of a shard map to packets far apart in the frame
-      // (i -> i * M mod per_shard, M coprime to per_shard), so a batch does not sit in
-      // one expensive region (glass costs ~100x a floor packet)
-      long long j = ((long long)ps.next * P.scatter_mul) % per_shard;
+      // ticket -> packet through the cost-sorted order (probe_kernel / order_kernel):
+      // expensive packets (refractive, then reflective first hits) are handed out first,
+      // the frame ends on cheap ones, so no wave is left alone with a 100x packet
+      long long g = (long long)ps.next * PACKET_SHARDS + ps.shard;
       ++ps.next;
-      long long id = j * PACKET_SHARDS + ps.shard;
-      if (id < (long long)P.n_packets) return (int)id;
+      if (g < (long long)P.n_packets) return P.order[g];
     }
     int got = 0, want = 0;
     if (lane == 0) {
       // estimate of what is left from the last ticket we saw; first call: everything
       int left = per_shard - ps.end;
       want = left / P.batch_div;
-      want = want < 1 ? 1 : (want > 16 ? 16 : want);
+      // tickets are cost-sorted: one at a time while in the refractive class (a packet
+      // there can cost 100x the average), at most 4 in the reflective class
+      long long g = (long long)ps.end * PACKET_SHARDS;
+      int cap = g < (long long)P.class_totals[3] ? 1
+                : (g < (long long)P.class_totals[3] + (long long)P.class_totals[2] ? 4 : 16);
+      want = want < 1 ? 1 : (want > cap ? cap : want);
       got = (int)atomicAdd(P.tile_counter + ps.shard * 32, (unsigned)want);
     }
     got = wave_uniform(got);
@@ -698,6 +702,135 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   }
 }
 
+// ---- packet cost classes (scheduling only; never affects a pixel value) ---------------
+// One packet costs between ~2 rays per sample (diffuse floor) and ~100 (glass: a binary
+// ray tree of depth wMaxDepth).  probe_kernel shoots 4 rays per packet and classifies
+// it by the material of the first hit; order_kernel then counting-sorts the packets,
+// most expensive class first (stable, no atomics).
+//   class 3 refractive | 2 reflective (non-zero reflection weight) | 1 other hit | 0 miss
+constexpr int PROBE_CLASSES = 4;
+
+DEVI void decode_packet(const RenderParams &P, int packet, int sub, int &px, int &py, bool &inside) {
+  const int tile_px = P.tile_w * P.tile_h;
+  const int ltile = packet / P.groups_per_tile, grp = packet - ltile * P.groups_per_tile;
+  const int gtile = P.rank + ltile * P.nranks;
+  int pit = (P.spp <= 64) ? grp * P.px_per_packet + sub % P.px_per_packet : grp;
+  px = (gtile % P.tiles_x) * P.tile_w + pit % P.tile_w;
+  py = (gtile / P.tiles_x) * P.tile_h + pit / P.tile_w;
+  inside = pit < tile_px && px < P.W && py < P.H;
+}
+
+template <bool PRUNE>
+__global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
+  extern __shared__ unsigned lds[];
+  __shared__ unsigned hist[PROBE_CLASSES];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
+  if (threadIdx.x < PROBE_CLASSES) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int span = P.probe_span;  // packets per block (multiple of 64)
+  const int first = blockIdx.x * span;
+  Counters cn = {0, 0, 0};
+  for (int base = first; base < first + span; base += 64) {  // uniform trip count per block
+    const int packet = base + (int)(threadIdx.x >> 2), sub = (int)(threadIdx.x & 3);
+    bool inside = false;
+    int px = 0, py = 0;
+    const bool valid = packet < P.n_packets && packet < first + span;
+    if (valid) decode_packet(P, packet, sub, px, py, inside);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (inside) {
+      float fi = (float)px + (0.25f + 0.5f * (float)(sub & 1));
+      float fj = (float)(P.H - 1 - py) + (0.25f + 0.5f * (float)(sub >> 1));
+      get_ray(P, fi, fj, 0.5f, 0.5f, o, d);
+    }
+    float t;
+    int p;
+    traverse<false, PRUNE, false>(P, stack, lane, inside, o, d, 0.0f, t, p, cn);
+    int cls = 0;
+    if (inside && p >= 0) {
+      int mat = __float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].y);
+      const float *M = P.materials + (size_t)mat * 12;
+      float refl = M[7];
+      bool mirror = (M[3] * refl != 0) || (M[4] * refl != 0) || (M[5] * refl != 0);
+      cls = (M[8] != 0) ? 3 : (mirror ? 2 : 1);
+    }
+    cls = max(cls, __shfl_xor(cls, 1));
+    cls = max(cls, __shfl_xor(cls, 2));
+    if (valid && sub == 0) {
+      P.pclass[packet] = (unsigned char)cls;
+      atomicAdd(&hist[cls], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < PROBE_CLASSES) P.block_hist[blockIdx.x * PROBE_CLASSES + threadIdx.x] = hist[threadIdx.x];
+}
+
+// Stable counting sort of the packets by class, heaviest first.  Block b owns the same
+// packet span as in probe_kernel; its output offsets come from the per-block histograms.
+__global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
+  __shared__ unsigned base[PROBE_CLASSES];      // running output offset per class
+  __shared__ unsigned red[PROBE_CLASSES][4];    // per-wave partials
+  __shared__ unsigned wcount[4][PROBE_CLASSES];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int nb = gridDim.x;
+  // totals of every class and the counts of the blocks before this one
+  unsigned tot[PROBE_CLASSES] = {0, 0, 0, 0}, before[PROBE_CLASSES] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nb; b += 256)
+    for (int c = 0; c < PROBE_CLASSES; ++c) {
+      unsigned v = P.block_hist[b * PROBE_CLASSES + c];
+      tot[c] += v;
+      if (b < (int)blockIdx.x) before[c] += v;
+    }
+  // block reduce (8 values): wave shuffles then LDS
+  unsigned vals[2 * PROBE_CLASSES];
+  for (int c = 0; c < PROBE_CLASSES; ++c) { vals[c] = tot[c]; vals[PROBE_CLASSES + c] = before[c]; }
+  __shared__ unsigned part[4][2 * PROBE_CLASSES];
+  for (int k = 0; k < 2 * PROBE_CLASSES; ++k) {
+    unsigned v = vals[k];
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) v += __shfl_xor(v, dlt);
+    if (lane == 0) part[wib][k] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < PROBE_CLASSES)
+    P.class_totals[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                                  part[3][threadIdx.x];
+  if (threadIdx.x < PROBE_CLASSES) {
+    int c = threadIdx.x;
+    unsigned heavier = 0;
+    for (int h = c + 1; h < PROBE_CLASSES; ++h)
+      heavier += part[0][h] + part[1][h] + part[2][h] + part[3][h];
+    base[c] = heavier + part[0][PROBE_CLASSES + c] + part[1][PROBE_CLASSES + c] + part[2][PROBE_CLASSES + c] +
+              part[3][PROBE_CLASSES + c];
+  }
+  __syncthreads();
+  (void)red;
+  const int span = P.probe_span;
+  const int first = blockIdx.x * span;
+  for (int b0 = first; b0 < first + span; b0 += 256) {
+    const int packet = b0 + (int)threadIdx.x;
+    const bool valid = packet < P.n_packets && packet < first + span;
+    const int cls = valid ? (int)P.pclass[packet] : -1;
+    unsigned rank = 0;
+    for (int c = 0; c < PROBE_CLASSES; ++c) {
+      unsigned long long m = __ballot(cls == c);
+      if (cls == c) rank = (unsigned)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (lane == 0) wcount[wib][c] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    if (valid) {
+      unsigned off = base[cls] + rank;
+      for (int w = 0; w < wib; ++w) off += wcount[w][cls];
+      P.order[off] = packet;
+    }
+    __syncthreads();
+    if (threadIdx.x < PROBE_CLASSES)
+      base[threadIdx.x] += wcount[0][threadIdx.x] + wcount[1][threadIdx.x] + wcount[2][threadIdx.x] +
+                           wcount[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
 // avgColors (Surfaces.hs:15-18) per pixel: sum of the sample colours divided by the
 // count.  One thread per local pixel; the sum is the exact fixed-point total rounded
 // once to fp32 (the reference rounds after every addition: <= a few ulp apart).
@@ -731,6 +864,13 @@ static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s)
 }
 
 static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
+  if (p.n_packets > 0) {
+    if (cfg.prune)
+      hipLaunchKernelGGL((probe_kernel<true>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes, s, p);
+    else
+      hipLaunchKernelGGL((probe_kernel<false>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes, s, p);
+    hipLaunchKernelGGL(order_kernel, dim3(p.probe_blocks), dim3(256), 0, s, p);
+  }
   if (cfg.prune) {
     if (cfg.count) launch_t<true, true>(p, cfg, s);
     else launch_t<true, false>(p, cfg, s);
