@@ -114,6 +114,7 @@ DEVICE_SYMBOLS = [
     "rt_init", "rt_shutdown", "rt_upload_scene", "rt_set_camera", "rt_set_samples",
     "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
+    "rt_wave_diag",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_build_bvh",
@@ -214,6 +215,7 @@ def device_lib() -> C.CDLL:
         L.rt_assemble_async.argtypes = [vp, vp, i32, C.c_size_t, vp, vp]
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
         L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.rt_wave_diag.argtypes = [vp, C.POINTER(u64), i32]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
         L.rt_abi_version.restype = C.c_int
@@ -473,6 +475,13 @@ class Renderer:
         st = Stats()
         self._check(self.lib.rt_collect(self._h, stream or None, C.byref(st)), "rt_collect")
         return st
+
+    def wave_diag(self, n_waves: int) -> np.ndarray:
+        """[n_waves, 2] (lifetime ticks @100 MHz, rays) of the last render."""
+        out = np.zeros((n_waves, 2), np.uint64)
+        self._check(self.lib.rt_wave_diag(self._h, out.ctypes.data_as(C.POINTER(u64)), n_waves),
+                    "rt_wave_diag")
+        return out
 
     def close(self) -> None:
         if self._h:

@@ -265,6 +265,8 @@ int prepare(rt_ctx *c, uint32_t flags) {
     int ppp = std::max(1, 64 / c->spp);
     size_t n_packets = (size_t)c->tiling.n_local_tiles *
                        ((size_t)(c->tiling.tile_w * c->tiling.tile_h + ppp - 1) / ppp);
+    if (n_packets >= (1u << 24)) return fail(c, RT_ERR_LIMIT, "too many packets (%zu)", n_packets);
+    n_packets *= (size_t)ppp;  // order entries: a refractive packet expands to one entry per pixel
     if (n_packets > c->order_cap || !c->d_order) {
       if (c->d_order) (void)hipFree(c->d_order);
       if (c->d_pclass) (void)hipFree(c->d_pclass);
@@ -417,7 +419,7 @@ int rt_init(int device, rt_ctx **out) {
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void **)&c->d_stats, 256) == hipSuccess;
+            hipMalloc((void **)&c->d_stats, (16 + 2 * 16384) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
     return RT_ERR_DEVICE;
@@ -574,6 +576,16 @@ int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, 
   int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, s, d_rgb, d_rgb8, n);
   HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+/* diagnostics: per-wave (lifetime in 100 MHz ticks, rays) pairs of the last render */
+int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
+  if (!c || !out || max_waves < 1) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  int n = std::min<int>(max_waves, 16384);
+  HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

@@ -67,13 +67,13 @@ struct RenderParams {
   int stack_depth, trace_zero_weight;
   int n_packets, groups_per_tile;     // packet = group of whole pixels; n_local_tiles * groups_per_tile
   int px_per_packet, chunks_per_packet;  // max(1, 64 / spp) pixels; ceil(spp / 64) chunks of 64 samples
-  int boxes_safe, pad3;                  // all node-box coordinates are 0 or in [2^-36, 2^59] (exact-reciprocal path)
+  int boxes_safe, split_refractive;                  // all node-box coordinates are 0 or in [2^-36, 2^59] (exact-reciprocal path)
   int batch_div, packets_per_shard;                   // guided packet batches: left_in_shard / batch_div, clamped to [1,16]
   // cost-sorted packet order (probe_kernel -> order_kernel)
   unsigned char *pclass;                 // [n_packets] cost class
   unsigned *block_hist;                  // [probe_blocks][4]
-  unsigned *class_totals;                // [4] packets per class (written by order_kernel)
-  int *order;                            // [n_packets] ticket -> packet
+  unsigned *class_totals;                // [0..3] packets per class, [4] order entries, [5] refractive entries
+  int *order;                            // ticket -> (packet << 7) | code, cost-sorted
   int probe_blocks, probe_span;          // blocks and packets per block (multiple of 256)
 };
 

@@ -352,8 +352,14 @@ struct PacketSrc {
   int next, end, shard;   // ids next .. end-1 of `shard` are owned by this wave
   int tries;              // shards found exhausted so far
 };
+// Order entries are (packet << 7) | code: code 127 = the whole packet, otherwise ONE pixel
+// of it (refractive packets are handed out pixel by pixel: a wave is never alone with
+// more than one pixel's ray tree).  class_totals[4] = number of entries, [5] = entries of
+// the refractive class, both written by order_kernel.
+constexpr int ENTRY_WHOLE = 127;
 DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
-  const int per_shard = P.packets_per_shard;
+  const long long n_entries = (long long)P.class_totals[4];
+  const int per_shard = (int)((n_entries + PACKET_SHARDS - 1) / PACKET_SHARDS);
   while (ps.tries < PACKET_SHARDS) {
     while (ps.next < ps.end) {
       // ticket -> packet through the cost-sorted order (probe_kernel / order_kernel):
@@ -361,7 +367,7 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
       // the frame ends on cheap ones, so no wave is left alone with a 100x packet
       long long g = (long long)ps.next * PACKET_SHARDS + ps.shard;
       ++ps.next;
-      if (g < (long long)P.n_packets) return P.order[g];
+      if (g < n_entries) return P.order[g];
     }
     int got = 0, want = 0;
     if (lane == 0) {
@@ -371,8 +377,8 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
       // tickets are cost-sorted: one at a time while in the refractive class (a packet
       // there can cost 100x the average), at most 4 in the reflective class
       long long g = (long long)ps.end * PACKET_SHARDS;
-      int cap = g < (long long)P.class_totals[3] ? 1
-                : (g < (long long)P.class_totals[3] + (long long)P.class_totals[2] ? 4 : 16);
+      int cap = g < (long long)P.class_totals[5] ? 2
+                : (g < (long long)P.class_totals[5] + (long long)P.class_totals[2] ? 4 : 16);
       want = want < 1 ? 1 : (want > cap ? cap : want);
       got = (int)atomicAdd(P.tile_counter + ps.shard * 32, (unsigned)want);
     }
@@ -445,13 +451,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     unsigned pix;  // local pixel index: ltile * tile_px + (pixel in tile)
     int px = 0, py = 0, smp = 0;
     if (level == 1) {
-      const int ltile = cur_packet / P.groups_per_tile, grp = cur_packet - ltile * P.groups_per_tile;
+      const int packet_id = cur_packet >> 7, code = cur_packet & 127;
+      const int ltile = packet_id / P.groups_per_tile, grp = packet_id - ltile * P.groups_per_tile;
       const int gtile = P.rank + ltile * P.nranks;
       const int tx0 = (gtile % P.tiles_x) * P.tile_w;
       const int ty0 = (gtile / P.tiles_x) * P.tile_h;
       int pit;
       bool in_packet;
-      if (P.spp <= 64) {
+      if (P.spp <= 64 && code != ENTRY_WHOLE) {  // single-pixel entry
+        smp = lane;
+        pit = grp * P.px_per_packet + code;
+        in_packet = lane < P.spp;
+      } else if (P.spp <= 64) {
         int sub = lane / P.spp;
         smp = lane - sub * P.spp;
         pit = grp * P.px_per_packet + sub;
@@ -694,6 +705,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     atomicAdd(&P.stats[9], life);
     atomicMax(&P.stats[10], life);
     atomicAdd(&P.stats[11], 1ull);
+    // per-wave diagnostics (rt_wave_diag): lifetime ticks, rays processed
+    P.stats[16 + gwave * 2] = life;
+    P.stats[17 + gwave * 2] = n_primary + n_shadow + n_refl + n_refr;
   }
   if (COUNT) {
     atomicAdd(&P.stats[4], (unsigned long long)cn.box);
@@ -792,16 +806,25 @@ __global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
     if (lane == 0) part[wib][k] = v;
   }
   __syncthreads();
+  // a refractive packet becomes one entry per pixel (EXP entries), every other packet one
+  // (measured: per-pixel entries cost more in 4..16-lane primary chunks than they save in
+  //  tail on every shipped workload, so the split is off unless split_refractive is set)
+  const unsigned EXP = (P.split_refractive && P.spp <= 64 && P.px_per_packet > 1) ? (unsigned)P.px_per_packet : 1u;
   if (blockIdx.x == 0 && threadIdx.x < PROBE_CLASSES)
     P.class_totals[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
                                   part[3][threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned t3 = part[0][3] + part[1][3] + part[2][3] + part[3][3];
+    P.class_totals[4] = (unsigned)P.n_packets + (EXP - 1) * t3;
+    P.class_totals[5] = EXP * t3;
+  }
   if (threadIdx.x < PROBE_CLASSES) {
     int c = threadIdx.x;
     unsigned heavier = 0;
     for (int h = c + 1; h < PROBE_CLASSES; ++h)
-      heavier += part[0][h] + part[1][h] + part[2][h] + part[3][h];
-    base[c] = heavier + part[0][PROBE_CLASSES + c] + part[1][PROBE_CLASSES + c] + part[2][PROBE_CLASSES + c] +
-              part[3][PROBE_CLASSES + c];
+      heavier += (part[0][h] + part[1][h] + part[2][h] + part[3][h]) * (h == 3 ? EXP : 1u);
+    base[c] = heavier + (part[0][PROBE_CLASSES + c] + part[1][PROBE_CLASSES + c] + part[2][PROBE_CLASSES + c] +
+                         part[3][PROBE_CLASSES + c]) * (c == 3 ? EXP : 1u);
   }
   __syncthreads();
   (void)red;
@@ -819,14 +842,19 @@ __global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
     }
     __syncthreads();
     if (valid) {
-      unsigned off = base[cls] + rank;
-      for (int w = 0; w < wib; ++w) off += wcount[w][cls];
-      P.order[off] = packet;
+      unsigned r = rank;
+      for (int w = 0; w < wib; ++w) r += wcount[w][cls];
+      if (cls == 3 && EXP > 1) {
+        unsigned off = base[3] + r * EXP;
+        for (unsigned k = 0; k < EXP; ++k) P.order[off + k] = (packet << 7) | (int)k;
+      } else {
+        P.order[base[cls] + r] = (packet << 7) | ENTRY_WHOLE;
+      }
     }
     __syncthreads();
     if (threadIdx.x < PROBE_CLASSES)
-      base[threadIdx.x] += wcount[0][threadIdx.x] + wcount[1][threadIdx.x] + wcount[2][threadIdx.x] +
-                           wcount[3][threadIdx.x];
+      base[threadIdx.x] += (wcount[0][threadIdx.x] + wcount[1][threadIdx.x] + wcount[2][threadIdx.x] +
+                            wcount[3][threadIdx.x]) * (threadIdx.x == 3 ? EXP : 1u);
     __syncthreads();
   }
 }

@@ -16,4 +16,12 @@ for wl in sys.argv[1:] or ["c2"]:
           f"waves {st.n_waves}  wave avg {st.wave_ticks_sum/max(1,st.n_waves)/100:.1f} us  "
           f"wave max {st.wave_ticks_max/100:.1f} us "
           f"rays {st.rays_total}")
+    wd = r.wave_diag(int(st.n_waves)).astype(float)
+    import numpy as np
+    life = wd[:, 0] / 100.0
+    pc = np.percentile(life, [0, 10, 50, 90, 99, 100])
+    top = np.argsort(life)[-3:]
+    print("   wave lifetime us percentiles 0/10/50/90/99/100:", " ".join(f"{x:.0f}" for x in pc),
+          " rays/wave min/med/max:", int(wd[:, 1].min()), int(np.median(wd[:, 1])), int(wd[:, 1].max()),
+          " slowest waves rays:", [int(wd[i, 1]) for i in top])
     r.close()
