@@ -30,6 +30,8 @@ import torch
 import torch.distributed as dist
 
 import rt_amd as rt
+import importlib
+rtd = importlib.import_module("ray-tracer_amd.distributed")
 
 PEAK_VALU_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBPS = 8000.0     # HBM3E spec
@@ -117,51 +119,31 @@ def main() -> None:
     r = rt.Renderer(local_rank)
     r.set_world(world)
     r.set_samples(grids)
-    r.set_partition(rank, world_size)
-    til = r.tiling()
-    tile_floats = til.tile_w * til.tile_h * 3
-    stride = ((til.n_tiles + world_size - 1) // world_size) * tile_floats
-
-    # a dedicated (non-null) torch stream: the library launches on it, torch's events and
-    # RCCL's stream ordering see it
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
+    df = rtd.DistributedFrame(r, rank, world_size, dev, pipeline=2)
+    stream = df.render_stream.cuda_stream   # a dedicated non-null stream; the kernels run on it
     assert stream != 0
-    frame = torch.zeros(world.height * world.width * 3, dtype=torch.float32, device=dev)
-    if world_size > 1:
-        mine = torch.zeros(stride, dtype=torch.float32, device=dev)
-        gathered = torch.zeros(world_size * stride, dtype=torch.float32, device=dev) if rank == 0 else None
-        glist = list(gathered.split(stride)) if rank == 0 else None
-
-    def step():
-        if world_size == 1:
-            r.render_async(frame.data_ptr(), 0, args.flags, stream)
-        else:
-            r.render_tiles_async(mine.data_ptr(), args.flags, stream)
-            dist.gather(mine, glist, dst=0)
-            if rank == 0:
-                r.assemble_async(gathered.data_ptr(), world_size, stride, frame.data_ptr(), stream)
+    frame = df.frame
 
     def fence():
+        df.finish()
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        df.submit(args.flags)
     fence()
     st = r.collect(stream)           # per-frame ray counters of this rank (same every frame)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
-    ev0.record()
+    ev0.record(df.render_stream)
     for _ in range(args.steps):
-        step()
-    ev1.record()
+        df.submit(args.flags)
+    ev1.record(df.render_stream)
     fence()
     dt = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)   # on the stream the kernel runs on
+    gpu_ms = ev0.elapsed_time(ev1)   # HIP events on the stream the kernels are launched on
 
     rays = torch.tensor([st.rays_total, st.rays_primary, st.rays_shadow,
                          st.rays_reflection + st.rays_refraction], dtype=torch.float64, device=dev)
