@@ -477,8 +477,8 @@ class Renderer:
         return st
 
     def wave_diag(self, n_waves: int) -> np.ndarray:
-        """[n_waves, 2] (lifetime ticks @100 MHz, rays) of the last render."""
-        out = np.zeros((n_waves, 2), np.uint64)
+        """[n_waves, 4] (lifetime ticks @100 MHz, rays, start tick, dry tick) of the last render."""
+        out = np.zeros((n_waves, 4), np.uint64)
         self._check(self.lib.rt_wave_diag(self._h, out.ctypes.data_as(C.POINTER(u64)), n_waves),
                     "rt_wave_diag")
         return out

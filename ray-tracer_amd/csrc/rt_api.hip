@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,7 @@ struct rt_ctx {
   size_t d_ids_count = 0;
   bool prepared = false;
   int stack_depth = 8;
+  int split_mode = -1;  // RT_SPLIT_REFRACTIVE: 0 off, 1 on, -1 auto (tuning knob, never changes a pixel)
 };
 
 namespace {
@@ -351,6 +353,10 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (cfg.grid * WAVES_PER_BLOCK > c->scratch_waves)
     return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
 
+  // Refractive packets (a binary ray tree per sample) are handed out pixel by pixel when the
+  // rank has few packets per wave: the frame then ends on quarter-size work items.
+  p.split_refractive = c->split_mode >= 0 ? c->split_mode
+                                           : (p.n_packets < 48 * cfg.grid * WAVES_PER_BLOCK ? 1 : 0);
   p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
@@ -416,10 +422,11 @@ int rt_init(int device, rt_ctx **out) {
     return RT_ERR_DEVICE;
   }
   c->n_cus = prop.multiProcessorCount;
+  if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void **)&c->d_stats, (16 + 2 * 16384) * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
     return RT_ERR_DEVICE;
@@ -585,7 +592,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   int n = std::min<int>(max_waves, 16384);
-  HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

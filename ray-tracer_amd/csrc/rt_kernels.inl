@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   unsigned long long n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
   Counters cn = {0, 0, 0};
   const unsigned long long wave_t0 = wall_clock64();
+  unsigned long long t_dry = wave_t0;
 
   if (lane < 32) cnt[lane] = 0u;
   bool more_packets = P.max_depth >= 1;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       if (cur_packet < 0 && more_packets) {
         cur_packet = fetch_packet(P, lane, psrc);
         cur_chunk = 0;
-        if (cur_packet < 0) more_packets = false;
+        if (cur_packet < 0) { more_packets = false; t_dry = wall_clock64(); }
       }
       if (cur_packet >= 0) level = 1;
       else
@@ -706,8 +707,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     atomicMax(&P.stats[10], life);
     atomicAdd(&P.stats[11], 1ull);
     // per-wave diagnostics (rt_wave_diag): lifetime ticks, rays processed
-    P.stats[16 + gwave * 2] = life;
-    P.stats[17 + gwave * 2] = n_primary + n_shadow + n_refl + n_refr;
+    P.stats[16 + gwave * 4] = life;
+    P.stats[17 + gwave * 4] = n_primary + n_shadow + n_refl + n_refr;
+    P.stats[18 + gwave * 4] = wave_t0;
+    P.stats[19 + gwave * 4] = t_dry - wave_t0;  // when the packet supply ran dry for this wave
   }
   if (COUNT) {
     atomicAdd(&P.stats[4], (unsigned long long)cn.box);

@@ -4,11 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import rt_amd as rt
+NR = int(os.environ.get("NRANKS", "1"))
 for wl in sys.argv[1:] or ["c2"]:
     world = bench.make_world(wl)
     grids = rt.generate_grids(bench.SEED, world.width + 10, world.camera.aa)
     r = rt.Renderer(0)
-    r.set_world(world); r.set_samples(grids)
+    r.set_world(world); r.set_samples(grids); r.set_partition(0, NR)
     for i in range(3):
         rgb, _, st = r.render(0)
     til = r.tiling()
@@ -25,3 +26,10 @@ for wl in sys.argv[1:] or ["c2"]:
           " rays/wave min/med/max:", int(wd[:, 1].min()), int(np.median(wd[:, 1])), int(wd[:, 1].max()),
           " slowest waves rays:", [int(wd[i, 1]) for i in top])
     r.close()
+    t0 = wd[:, 2] - wd[:, 2].min()
+    dry = (t0 + wd[:, 3]) / 100.0
+    end = (t0 + wd[:, 0]) / 100.0
+    print("   start us p50/p100:", f"{np.percentile(t0/100,50):.0f} {t0.max()/100:.0f}",
+          " dry us p0/p50/p100:", " ".join(f"{x:.0f}" for x in np.percentile(dry, [0, 50, 100])),
+          " end us p0/p50/p99/p100:", " ".join(f"{x:.0f}" for x in np.percentile(end, [0, 50, 99, 100])),
+          " drain (end-dry) us p50/p90/p100:", " ".join(f"{x:.0f}" for x in np.percentile(end - dry, [50, 90, 100])))
