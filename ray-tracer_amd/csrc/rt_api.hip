@@ -28,6 +28,8 @@ struct rt_ctx {
   float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
+  int n_node_recs = 0, n_prim_recs = 0;
+  int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
   bool have_scene = false;
   // camera / samples
   rt_camera cam{};
@@ -58,7 +60,7 @@ struct rt_ctx {
   size_t d_ids_count = 0;
   bool prepared = false;
   int stack_depth = 8;
-  int split_mode = -1;  // RT_SPLIT_REFRACTIVE: 0 off, 1 on, -1 auto (tuning knob, never changes a pixel)
+  int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
 };
 
 namespace {
@@ -343,9 +345,18 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   cfg.lds_bytes = lds_bytes_for(c->stack_depth);
   cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
   cfg.count = (flags & RT_FLAG_COUNT_TESTS) != 0;
+  // Small scenes (every shipped benchmark scene but bench3) are staged into each block's LDS:
+  // node/primitive fetches then cost an LDS read instead of a trip through TA/L1.  The copy
+  // must leave room for 4 blocks (16 waves) per CU: 160 KiB / 4 = 40 KiB per block.
+  p.n_node_recs = c->n_node_recs;
+  p.n_prim_recs = c->n_prim_recs;
+  cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16;
+  cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
+  if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
+  cfg.lds_bytes += cfg.lds_scene_bytes;
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_bytes);
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -423,6 +434,7 @@ int rt_init(int device, rt_ctx **out) {
   }
   c->n_cus = prop.multiProcessorCount;
   if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
+  if (const char *e = std::getenv("RT_LDS_SCENE")) c->lds_scene_mode = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
@@ -485,6 +497,8 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if ((rc = upload(c, &c->d_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
   if ((rc = upload(c, &c->d_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;
+  c->n_node_recs = (int)(rp.nodes.size() / 16);
+  c->n_prim_recs = (int)(rp.prims.size() / 16);
   c->has_root = sc->n_nodes > 0;
   c->tree_depth = rp.max_depth;
   c->boxes_safe = 1;

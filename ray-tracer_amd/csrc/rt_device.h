@@ -33,6 +33,7 @@ constexpr int NODE_F4 = 4;
 //   i[12] kind (0 sphere, 1 triangle)  i[13] material  i[14] object id
 //   i[15] number of records in this leaf (valid in the leaf's first record)
 constexpr int PRIM_F4 = 4;
+constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)
 
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
 constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
@@ -75,19 +76,22 @@ struct RenderParams {
   unsigned *class_totals;                // [0..3] packets per class, [4] order entries, [5] refractive entries
   int *order;                            // ticket -> (packet << 7) | code, cost-sorted
   int probe_blocks, probe_span;          // blocks and packets per block (multiple of 256)
+  int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
 };
 
 struct LaunchCfg {
   int grid, block;
   size_t lds_bytes;
   bool prune, count;
+  bool lds_scene;           // render from the block's LDS copy of the scene
+  size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
 };
 
 // one per arithmetic mode (separate translation units, different -ffp-contract)
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
-int occupancy_strict(bool prune, bool count, size_t lds_bytes);
-int occupancy_fma(bool prune, bool count, size_t lds_bytes);
+int occupancy_strict(bool prune, bool count, bool lds_scene, size_t lds_bytes);
+int occupancy_fma(bool prune, bool count, bool lds_scene, size_t lds_bytes);
 
 inline size_t lds_bytes_for(int stack_depth) {
   return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + TAG_SLOTS + 32) * 4;

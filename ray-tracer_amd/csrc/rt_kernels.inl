@@ -187,8 +187,21 @@ constexpr float BEHIND = -0.000244140625f;
 // Tie rule of the closest-hit form: t < best, or t == best and a larger record
 // index (see rt_device.h).  NaN distances never win (documented deviation: the
 // reference's Ord instance lets a NaN stick in two corner cases).
-template <bool ANY, bool PRUNE, bool COUNT>
-DEVI void traverse(const RenderParams &P, unsigned *stack, int lane, bool active, V3 o, V3 d,
+// Scene records: HBM (through L1/L2) or, when the whole scene fits, the block's LDS copy.
+// LDS records are LDS_REC_F4 = 5 float4 (80 B) apart: 20 dwords mod 64 banks walks all 16
+// four-bank groups, so a 16-lane ds_read_b128 group reading 16 different records is
+// conflict-free (64-B spacing would fold them onto 4 groups).
+template <bool LDS>
+DEVI const float4 *node_rec(const RenderParams &P, const float4 *sc, int idx) {
+  return LDS ? sc + (size_t)idx * LDS_REC_F4 : P.nodes + (size_t)idx * NODE_F4;
+}
+template <bool LDS>
+DEVI const float4 *prim_rec(const RenderParams &P, const float4 *sc, int idx) {
+  return LDS ? sc + (size_t)(P.n_node_recs + idx) * LDS_REC_F4 : P.prims + (size_t)idx * PRIM_F4;
+}
+
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
+DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, bool active, V3 o, V3 d,
                    float tlimit, float &best_t, int &best_p, Counters &cn) {
   best_t = ANY ? tlimit : INFINITY;
   best_p = -1;
@@ -200,7 +213,7 @@ DEVI void traverse(const RenderParams &P, unsigned *stack, int lane, bool active
   const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
   while (cur != STOP) {
     if (cur >= 0) {
-      const float4 *np = P.nodes + (size_t)cur * NODE_F4;
+      const float4 *np = node_rec<LDS>(P, sc, cur);
       float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
       int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
       float le0, le1, le2, lx0, lx1, lx2, re0, re1, re2, rx0, rx1, rx2;
@@ -245,11 +258,11 @@ DEVI void traverse(const RenderParams &P, unsigned *stack, int lane, bool active
     } else {
       // leaf: records first .. first+count-1 (reversed list order)
       int first = -1 - cur;
-      const float4 *pp = P.prims + (size_t)first * PRIM_F4;
+      const float4 *pp = prim_rec<LDS>(P, sc, first);
       int count = __float_as_int(pp[3].w);
       bool done = false;
       for (int k = 0; k < count; ++k) {
-        const float4 *q = pp + (size_t)k * PRIM_F4;
+        const float4 *q = pp + (size_t)k * (LDS ? LDS_REC_F4 : PRIM_F4);
         float4 q0 = q[0], q1 = q[1], q3 = q[3];
         float t;
         bool ok;
@@ -396,13 +409,28 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
   return -1;
 }
 
-template <bool PRUNE, bool COUNT>
+template <bool PRUNE, bool COUNT, bool LDS>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
-  extern __shared__ unsigned lds[];
+  extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WAVES_PER_BLOCK + wib;
-  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
+  // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | tag table | level counters]
+  const float4 *sc = reinterpret_cast<const float4 *>(lds);
+  const int scene_words = LDS ? (P.n_node_recs + P.n_prim_recs) * LDS_REC_F4 * 4 : 0;
+  if (LDS) {
+    // the block's one and only barrier: stage the scene (a few KB) once per persistent block
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    const int n_f4 = (P.n_node_recs + P.n_prim_recs) * 4;
+    for (int i = threadIdx.x; i < n_f4; i += 256) {
+      const int rec = i >> 2, part = i & 3;
+      const float4 v = rec < P.n_node_recs ? P.nodes[(size_t)rec * NODE_F4 + part]
+                                           : P.prims[(size_t)(rec - P.n_node_recs) * PRIM_F4 + part];
+      dst[(size_t)rec * LDS_REC_F4 + part] = v;
+    }
+    __syncthreads();
+  }
+  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
   // volatile: lanes of one wave race on tag[] on purpose; the read-back must really
   // come from LDS (no store-to-load forwarding inside a lane)
   volatile unsigned *tag = stack + P.stack_depth * 64;
@@ -517,7 +545,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // ---- raytrace (RayTracer.hs:55-71): closest hit ----------------------------------
     float t;
     int p;
-    traverse<false, PRUNE, COUNT>(P, stack, lane, active, o, d, 0.0f, t, p, cn);
+    traverse<false, PRUNE, COUNT, LDS>(P, sc, stack, lane, active, o, d, 0.0f, t, p, cn);
     const bool hit = active && p >= 0;
     n_hits += __popcll(__ballot(hit));
 
@@ -525,7 +553,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       n_phits += __popcll(__ballot(hit));
       if (P.hit_ids && active) {
         uint32_t id = RT_HIT_NONE;
-        if (hit) id = (uint32_t)__float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].z);
+        if (hit) id = (uint32_t)__float_as_int(prim_rec<LDS>(P, sc, p)[3].z);
         P.hit_ids[((size_t)py * P.W + px) * P.spp + smp] = id;
       }
     }
@@ -534,7 +562,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     V3 pt = mk(0, 0, 0), n = mk(0, 1, 0), clr = mk(0, 0, 0);
     int mat = 0;
     if (hit) {
-      const float4 *q = P.prims + (size_t)p * PRIM_F4;
+      const float4 *q = prim_rec<LDS>(P, sc, p);
       float4 q3 = q[3];
       mat = __float_as_int(q3.y);
       pt = add(o, multiply(d, t));  // :63
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       float max_d = magnitude(l);
       float st;
       int sprim;
-      traverse<true, PRUNE, COUNT>(P, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
       n_shadow += __popcll(__ballot(hit));
       if (hit && sprim < 0) {
         V3 l_c = ld3(Lp + 9);
@@ -763,7 +791,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
     }
     float t;
     int p;
-    traverse<false, PRUNE, false>(P, stack, lane, inside, o, d, 0.0f, t, p, cn);
+    traverse<false, PRUNE, false, false>(P, nullptr, stack, lane, inside, o, d, 0.0f, t, p, cn);
     int cls = 0;
     if (inside && p >= 0) {
       int mat = __float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].y);
@@ -890,16 +918,19 @@ __global__ void resolve_kernel(const RenderParams P) {
 
 template <bool PRUNE, bool COUNT>
 static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
-  hipLaunchKernelGGL((render_kernel<PRUNE, COUNT>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s,
-                     p);
+  if (cfg.lds_scene && !COUNT)
+    hipLaunchKernelGGL((render_kernel<PRUNE, false, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
+  else
+    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false>), dim3(cfg.grid), dim3(cfg.block),
+                       cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
 }
 
 static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   if (p.n_packets > 0) {
     if (cfg.prune)
-      hipLaunchKernelGGL((probe_kernel<true>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes, s, p);
+      hipLaunchKernelGGL((probe_kernel<true>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
     else
-      hipLaunchKernelGGL((probe_kernel<false>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes, s, p);
+      hipLaunchKernelGGL((probe_kernel<false>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
     hipLaunchKernelGGL(order_kernel, dim3(p.probe_blocks), dim3(256), 0, s, p);
   }
   if (cfg.prune) {
@@ -917,15 +948,18 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, size_t lds_bytes) {
+static int occupancy(bool prune, bool count, bool lds_scene, size_t lds_bytes) {
   int n = 0;
   hipError_t e;
-  if (prune) {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false>, 256, lds_bytes);
+  if (lds_scene && !count) {
+    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true>, 256, lds_bytes);
+  } else if (prune) {
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false>, 256, lds_bytes);
   } else {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false>, 256, lds_bytes);
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false>, 256, lds_bytes);
   }
   return e == hipSuccess ? n : 0;
 }
