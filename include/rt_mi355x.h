@@ -226,7 +226,7 @@ int rt_quantize_async(rt_ctx *ctx, const float *d_rgb, uint8_t *d_rgb8, size_t n
                       void *hip_stream);
 
 /* Diagnostics of the last render, four words per persistent wave w (100 MHz ticks):
- * out[4w] lifetime, out[4w+1] rays it traversed, out[4w+2] start tick (absolute),
+ * out[4w] lifetime, out[4w+1] rays it traversed, out[4w+2] = (scheduling steps << 40) | (start tick mod 2^40),
  * out[4w+3] ticks after its start at which the packet supply ran dry.  max_waves <= 16384. */
 int rt_wave_diag(rt_ctx *ctx, uint64_t *out, int32_t max_waves);
 

@@ -28,7 +28,7 @@ struct rt_ctx {
   float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
-  int n_node_recs = 0, n_prim_recs = 0;
+  int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
   bool have_scene = false;
   // camera / samples
@@ -60,6 +60,8 @@ struct rt_ctx {
   size_t d_ids_count = 0;
   bool prepared = false;
   int stack_depth = 8;
+  int batches = 0;                 // RT_BATCHES
+  int refr_cap = 0, refl_cap = 0;  // RT_REFR_CAP / RT_REFL_CAP (0 = default)
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
 };
 
@@ -350,7 +352,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   // must leave room for 4 blocks (16 waves) per CU: 160 KiB / 4 = 40 KiB per block.
   p.n_node_recs = c->n_node_recs;
   p.n_prim_recs = c->n_prim_recs;
-  cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16;
+  p.n_materials = c->n_materials;
+  cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16 +
+                        (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
   cfg.lds_bytes += cfg.lds_scene_bytes;
@@ -368,6 +372,16 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   // rank has few packets per wave: the frame then ends on quarter-size work items.
   p.split_refractive = c->split_mode >= 0 ? c->split_mode
                                            : (p.n_packets < 48 * cfg.grid * WAVES_PER_BLOCK ? 1 : 0);
+  {
+    // a wave should come back for tickets at least ~RT_BATCHES times per frame: its estimate of
+    // what is left in the shard is one batch old, and an oversized last batch is the frame's tail
+    int waves_per_shard = std::max(1, cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);
+    int per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
+    int batches = c->batches > 0 ? c->batches : 8;
+    p.batch_cap = std::min(16, std::max(1, per_shard / (waves_per_shard * batches)));
+  }
+  p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 2;
+  p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 4;
   p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
@@ -378,6 +392,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.order = c->d_order;
   HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 16 * sizeof(unsigned long long), s));
+  // pixel accumulators start at zero (the kernel only adds, with atomics)
+  HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h * 3 * sizeof(long long), s));
   HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
@@ -435,10 +452,13 @@ int rt_init(int device, rt_ctx **out) {
   c->n_cus = prop.multiProcessorCount;
   if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_LDS_SCENE")) c->lds_scene_mode = std::atoi(e);
+  if (const char *e = std::getenv("RT_BATCHES")) c->batches = std::atoi(e);
+  if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
+  if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384) * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 16) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
     return RT_ERR_DEVICE;
@@ -497,6 +517,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if ((rc = upload(c, &c->d_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
   if ((rc = upload(c, &c->d_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;
+  c->n_materials = sc->n_materials;
   c->n_node_recs = (int)(rp.nodes.size() / 16);
   c->n_prim_recs = (int)(rp.prims.size() / 16);
   c->has_root = sc->n_nodes > 0;
@@ -605,7 +626,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   if (!c || !out || max_waves < 1) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
-  int n = std::min<int>(max_waves, 16384);
+  int n = std::min<int>(max_waves, 16384 + 4);  // the last 4 rows: phase sums of a profiling build
   HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }

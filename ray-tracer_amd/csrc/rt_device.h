@@ -77,6 +77,8 @@ struct RenderParams {
   int *order;                            // ticket -> (packet << 7) | code, cost-sorted
   int probe_blocks, probe_span;          // blocks and packets per block (multiple of 256)
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
+  int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
+  int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
 };
 
 struct LaunchCfg {

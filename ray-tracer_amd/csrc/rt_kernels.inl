@@ -342,6 +342,16 @@ DEVI int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 
+// Diagnostic build (-DRT_PROFILE_PHASES, never the shipped library): shader-clock stamps
+// around the phases of the scheduling loop, summed per wave into the rt_wave_diag area.
+#ifdef RT_PROFILE_PHASES
+#define PH_DECL unsigned long long ph_start = __builtin_amdgcn_s_memtime(), ph_t = ph_start, ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0, ph_lanes = 0
+#define PH_MARK(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#endif
+
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
@@ -364,49 +374,91 @@ DEVI long long to_fixed(float c) {
 struct PacketSrc {
   int next, end, shard;   // ids next .. end-1 of `shard` are owned by this wave
   int tries;              // shards found exhausted so far
+  // a ticket request in flight: the atomic's return value is NOT waited for when it is
+  // issued; it is consumed (first use = s_waitcnt) when the current batch has run out, a
+  // whole scheduling step later
+  bool pending;
+  int pend_want;
+  unsigned pend_got;      // valid in lane 0
+  // order_kernel's totals, read once per wave
+  long long n_entries;
+  int per_shard;
+  long long refr_entries, refl_end;
 };
 // Order entries are (packet << 7) | code: code 127 = the whole packet, otherwise ONE pixel
-// of it (refractive packets are handed out pixel by pixel: a wave is never alone with
-// more than one pixel's ray tree).  class_totals[4] = number of entries, [5] = entries of
-// the refractive class, both written by order_kernel.
+// of it (split_refractive).  class_totals[4] = number of entries, [5] = entries of the
+// refractive class, both written by order_kernel.
 constexpr int ENTRY_WHOLE = 127;
+DEVI void packet_src_init(const RenderParams &P, PacketSrc &ps, int shard) {
+  ps.next = ps.end = 0;
+  ps.shard = shard;
+  ps.tries = 0;
+  ps.pending = false;
+  ps.pend_want = 0;
+  ps.pend_got = 0;
+  ps.n_entries = (long long)P.class_totals[4];
+  ps.per_shard = (int)((ps.n_entries + PACKET_SHARDS - 1) / PACKET_SHARDS);
+  ps.refr_entries = (long long)P.class_totals[5];
+  ps.refl_end = ps.refr_entries + (long long)P.class_totals[2];
+}
+// Ask ps.shard for the next batch of tickets ("guided": the batch shrinks towards the end
+// of the shard so the tail stays one packet long).  Does not wait for the answer.
+DEVI void issue_ticket(const RenderParams &P, int lane, PacketSrc &ps) {
+  // estimate of what is left from the last ticket we saw; first call: everything
+  int left = ps.per_shard - ps.end;
+  int want = left / P.batch_div;
+  // tickets are cost-sorted: two at a time while in the refractive class (a packet there
+  // can cost 100x the average), at most 4 in the reflective class
+  long long g = (long long)ps.end * PACKET_SHARDS;
+  int cap = g < ps.refr_entries ? P.refr_cap : (g < ps.refl_end ? P.refl_cap : P.batch_cap);
+  want = want < 1 ? 1 : (want > cap ? cap : want);
+  unsigned got = 0;
+  if (lane == 0) got = atomicAdd(P.tile_counter + ps.shard * 32, (unsigned)want);
+  ps.pend_got = got;
+  ps.pend_want = want;
+  ps.pending = true;
+}
 DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
-  const long long n_entries = (long long)P.class_totals[4];
-  const int per_shard = (int)((n_entries + PACKET_SHARDS - 1) / PACKET_SHARDS);
-  while (ps.tries < PACKET_SHARDS) {
-    while (ps.next < ps.end) {
+  for (;;) {
+    if (ps.next < ps.end) {
       // ticket -> packet through the cost-sorted order (probe_kernel / order_kernel):
       // expensive packets (refractive, then reflective first hits) are handed out first,
       // the frame ends on cheap ones, so no wave is left alone with a 100x packet
       long long g = (long long)ps.next * PACKET_SHARDS + ps.shard;
       ++ps.next;
-      if (g < n_entries) return P.order[g];
+      // last ticket of the batch: request the next batch now, use it next time
+      if (ps.next == ps.end && !ps.pending && ps.tries < PACKET_SHARDS) issue_ticket(P, lane, ps);
+      if (g < ps.n_entries) return P.order[g];
+      continue;
     }
-    int got = 0, want = 0;
-    if (lane == 0) {
-      // estimate of what is left from the last ticket we saw; first call: everything
-      int left = per_shard - ps.end;
-      want = left / P.batch_div;
-      // tickets are cost-sorted: one at a time while in the refractive class (a packet
-      // there can cost 100x the average), at most 4 in the reflective class
-      long long g = (long long)ps.end * PACKET_SHARDS;
-      int cap = g < (long long)P.class_totals[5] ? 2
-                : (g < (long long)P.class_totals[5] + (long long)P.class_totals[2] ? 4 : 16);
-      want = want < 1 ? 1 : (want > cap ? cap : want);
-      got = (int)atomicAdd(P.tile_counter + ps.shard * 32, (unsigned)want);
-    }
-    got = wave_uniform(got);
-    want = wave_uniform(want);
-    if (got < per_shard) {
+    if (ps.tries >= PACKET_SHARDS) return -1;
+    if (!ps.pending) issue_ticket(P, lane, ps);
+    const int got = wave_uniform((int)ps.pend_got);  // the wait for the atomic is here
+    const int want = ps.pend_want;
+    ps.pending = false;
+    if (got < ps.per_shard) {
       ps.next = got;
-      ps.end = got + want < per_shard ? got + want : per_shard;
-    } else {  // shard exhausted: move on to the next one
-      ++ps.tries;
-      ps.shard = (ps.shard + 1) % PACKET_SHARDS;
+      ps.end = got + want < ps.per_shard ? got + want : ps.per_shard;
+    } else {
+      // Shard exhausted.  Do NOT probe the other shards with atomics (at the end of a frame
+      // every wave would: thousands of serialised same-address atomics per counter): read
+      // all counters with one coherent load, lane s <- shard s, and move to a shard that
+      // still has tickets, if any.  Counters only grow, so a stale value can only send us to
+      // a shard that turns out exhausted, which brings us back here.
+      unsigned v = 0xffffffffu;
+      if (lane < PACKET_SHARDS)
+        v = __hip_atomic_load(P.tile_counter + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned alive = (unsigned)__ballot(lane < PACKET_SHARDS && v < (unsigned)ps.per_shard);
       ps.next = ps.end = 0;
+      if (alive == 0) {
+        ps.tries = PACKET_SHARDS;  // nothing left anywhere
+      } else {
+        // first live shard after our own (rotation spreads the waves over the live shards)
+        const unsigned rot = (alive >> ps.shard) | (alive << (PACKET_SHARDS - ps.shard));
+        ps.shard = (ps.shard + __builtin_ctz(rot & 0xffffu)) % PACKET_SHARDS;
+      }
     }
   }
-  return -1;
 }
 
 template <bool PRUNE, bool COUNT, bool LDS>
@@ -417,7 +469,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WAVES_PER_BLOCK + wib;
   // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | tag table | level counters]
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
-  const int scene_words = LDS ? (P.n_node_recs + P.n_prim_recs) * LDS_REC_F4 * 4 : 0;
+  // (LDS builds also hold the material table behind the records: per-lane gathers of the
+  //  12 material floats then cost an LDS read instead of a trip through TA/L1)
+  const int rec_words = LDS ? (P.n_node_recs + P.n_prim_recs) * LDS_REC_F4 * 4 : 0;
+  const int scene_words = LDS ? rec_words + ((P.n_materials * 12 + 3) & ~3) : 0;
+  const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
   if (LDS) {
     // the block's one and only barrier: stage the scene (a few KB) once per persistent block
     float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -428,12 +484,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                                            : P.prims[(size_t)(rec - P.n_node_recs) * PRIM_F4 + part];
       dst[(size_t)rec * LDS_REC_F4 + part] = v;
     }
+    for (int i = threadIdx.x; i < P.n_materials * 12; i += 256) lds[rec_words + i] = __float_as_uint(P.materials[i]);
     __syncthreads();
   }
   unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
-  // volatile: lanes of one wave race on tag[] on purpose; the read-back must really
-  // come from LDS (no store-to-load forwarding inside a lane)
-  volatile unsigned *tag = stack + P.stack_depth * 64;
   unsigned *cnt = stack + P.stack_depth * 64 + TAG_SLOTS;  // cnt[L], L = 2..max_depth : rays queued at level L
 
   float *Q = P.scratch + gwave * P.scratch_stride;
@@ -445,36 +499,34 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   Counters cn = {0, 0, 0};
   const unsigned long long wave_t0 = wall_clock64();
   unsigned long long t_dry = wave_t0;
+  unsigned n_steps = 0;
+  PH_DECL;
 
   if (lane < 32) cnt[lane] = 0u;
-  bool more_packets = P.max_depth >= 1;
-  int cur_packet = -1, cur_chunk = 0;  // a packet = whole pixels; spp > 64 needs several chunks
-  PacketSrc psrc = {0, 0, (int)(gwave % PACKET_SHARDS), 0};
+  // wave-uniform summaries of cnt[] (bit L): which levels hold >= 64 rays / any ray; the
+  // level choice then needs no LDS round trips
+  unsigned full_mask = 0, nonempty_mask = 0;
+  // The NEXT packet is always fetched one step ahead (its ticket atomic and order[] load
+  // overlap the current step instead of heading the next one).
+  PacketSrc psrc;
+  packet_src_init(P, psrc, (int)(gwave % PACKET_SHARDS));
+  int cur_packet = P.max_depth >= 1 ? fetch_packet(P, lane, psrc) : -1;
+  int cur_chunk = 0;  // a packet = whole pixels; spp > 64 needs several chunks
 
   for (;;) {
-    __threadfence_block();  // this wave's queue / accumulator stores -> visible to its loads
     // ---- choose what to run: deepest full queue, else the next chunk of primaries,
     //      else the deepest non-empty queue -------------------------------------------
     int level = 0;
-    for (int L = P.max_depth; L >= 2; --L)
-      if ((int)cnt[L] >= 64) { level = L; break; }
-    if (level == 0) {
-      if (cur_packet < 0 && more_packets) {
-        cur_packet = fetch_packet(P, lane, psrc);
-        cur_chunk = 0;
-        if (cur_packet < 0) { more_packets = false; t_dry = wall_clock64(); }
-      }
-      if (cur_packet >= 0) level = 1;
-      else
-        for (int L = P.max_depth; L >= 2; --L)
-          if ((int)cnt[L] > 0) { level = L; break; }
-    }
+    if (full_mask) level = 31 - __clz((int)full_mask);
+    else if (cur_packet >= 0) level = 1;
+    else if (nonempty_mask) level = 31 - __clz((int)nonempty_mask);
     level = wave_uniform(level);
     if (level == 0) break;
+    ++n_steps;
+    PH_MARK(6);
 
     // ---- obtain 64 (or fewer) rays -------------------------------------------------
     bool active;
-    bool first_touch = false;  // level 1, first chunk of its pixels: store, do not add
     V3 o, d, W;
     float s0, s1;
     unsigned pix;  // local pixel index: ltile * tile_px + (pixel in tile)
@@ -501,14 +553,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         pit = grp;
         in_packet = smp < P.spp;
       }
-      first_touch = cur_chunk == 0;
-      if (++cur_chunk >= P.chunks_per_packet) cur_packet = -1;
       px = tx0 + pit % P.tile_w;
       py = ty0 + pit / P.tile_w;
       active = in_packet && (pit < tile_px) && (px < P.W) && (py < P.H);
       pix = (unsigned)(ltile * tile_px + pit);
       W = mk(1.0f, 1.0f, 1.0f);
       o = mk(0, 0, 0); d = mk(0, 0, 1); s0 = 0; s1 = 0;
+      PH_MARK(7);
       if (active) {
         // render (RayTracer.hs:18-23): list position k uses grid k mod n_grids
         size_t kpix = (size_t)py * P.W + px;
@@ -519,8 +570,22 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         s1 = F[5];
       }
       n_primary += __popcll(__ballot(active));
+      PH_MARK(8);
+#ifdef RT_PROFILE_PHASES
+      if (n_steps == 1) ph_acc[10] = __builtin_amdgcn_s_memtime() - ph_start;
+#endif
+      // Fetch the NEXT packet now, after this packet's sample loads have been consumed: the
+      // ticket atomic and the order[] load are then waited for a whole step later, not by
+      // the s_waitcnt of the sample loads (vector memory returns in order).
+      if (++cur_chunk >= P.chunks_per_packet) {
+        cur_packet = fetch_packet(P, lane, psrc);
+        cur_chunk = 0;
+        if (cur_packet < 0) t_dry = wall_clock64();
+      }
+      PH_MARK(9);
     } else {
-      int have = (int)cnt[level];
+      __threadfence_block();  // this wave's earlier queue stores -> visible to these loads
+      int have = wave_uniform((int)cnt[level]);
       int take = have < 64 ? have : 64;
       int idx = have - take + lane;
       active = lane < take;
@@ -535,6 +600,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         pix = __float_as_uint(ql[11 * QCAP + idx]);
       }
       if (lane == 0) cnt[level] = (unsigned)(have - take);
+      if (have - take < 64) full_mask &= ~(1u << level);
+      if (have - take == 0) nonempty_mask &= ~(1u << level);
       unsigned long long am = __ballot(active);
       unsigned long long rm = __ballot(active && (pix & SLOT_REFRACTION));
       n_refr += __popcll(rm);
@@ -542,11 +609,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       pix &= ~SLOT_REFRACTION;
     }
 
+    PH_MARK(0);
     // ---- raytrace (RayTracer.hs:55-71): closest hit ----------------------------------
     float t;
     int p;
     traverse<false, PRUNE, COUNT, LDS>(P, sc, stack, lane, active, o, d, 0.0f, t, p, cn);
     const bool hit = active && p >= 0;
+    PH_MARK(1);
     n_hits += __popcll(__ballot(hit));
 
     if (level == 1) {
@@ -574,7 +643,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         n = divide(subt(pt, mk(q0.x, q0.y, q0.z)), q0.w);  // getNormal, sphere (:76)
       }
     }
-    const float *M = P.materials + (size_t)mat * 12;
+    const float *M = LDS ? ldsM + mat * 12 : P.materials + (size_t)mat * 12;
     const V3 v = mk(-d.x, -d.y, -d.z);  // :65
 
     // getDirectColor (:81-106).  The reference folds the light list from the right:
@@ -591,7 +660,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       float max_d = magnitude(l);
       float st;
       int sprim;
+      PH_MARK(2);
       traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      PH_MARK(3);
       n_shadow += __popcll(__ballot(hit));
       if (hit && sprim < 0) {
         V3 l_c = ld3(Lp + 9);
@@ -604,12 +675,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       }
     }
 
+    PH_MARK(2);
     // ---- accumulate weight * direct colour into the PIXEL -----------------------------
-    // All rays of a pixel live in this wave (packets hold whole pixels), so a plain
-    // read-modify-write of the pixel's fixed-point sums is race-free across waves.
     // Inside the chunk, lanes of one pixel are first summed with a segmented wave scan
-    // over contiguous runs; the last lane of each run owns the update.  Runs of the
-    // same pixel that are not adjacent (rare) take turns through the LDS tag table.
+    // over contiguous runs; the last lane of each run adds the run's sum to the pixel's
+    // fixed-point accumulators (zeroed by the host before the launch).
     {
       V3 c = cmul(W, clr);
       const bool contrib = (level == 1) ? active : hit;
@@ -630,26 +700,21 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
           if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
         }
       }
-      long long *a = acc + (size_t)pix * 3;
-      if (level == 1 && first_touch) {
-        // first (only, for spp <= 64) chunk of these pixels: plain store, which also
-        // writes the zero of an all-miss pixel, so the buffer needs no clearing
-        if (tail) { a[0] = cr; a[1] = cg; a[2] = cb; }
-      } else {
-        bool pending = tail;
-        const unsigned h = (pix * 0x9E3779B1u) >> 24;  // TAG_SLOTS = 256
-        while (__ballot(pending)) {
-          if (pending) tag[h] = (unsigned)lane;
-          bool win = pending && tag[h] == (unsigned)lane;
-          if (win) {
-            a[0] += cr; a[1] += cg; a[2] += cb;
-            pending = false;
-          }
-          if (__ballot(pending)) __threadfence_block();
-        }
+      // the run's last lane adds the run's sum to the pixel: 64-bit integer atomics without
+      // return value (fire and forget; associative, so still order-independent and exact)
+#ifndef RT_DEBUG_NO_ACC
+      if (tail) {
+        unsigned long long *a = reinterpret_cast<unsigned long long *>(acc + (size_t)pix * 3);
+        if (cr) __hip_atomic_fetch_add(a + 0, (unsigned long long)cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cg) __hip_atomic_fetch_add(a + 1, (unsigned long long)cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cb) __hip_atomic_fetch_add(a + 2, (unsigned long long)cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+#else
+      if (tail && cr == 0x7fffffffffffffffll) acc[0] = cg + cb;
+#endif
     }
 
+    PH_MARK(4);
     // ---- getIndirectColor (:109-156): emit the child rays -----------------------------
     if (level < P.max_depth) {
       bool e_refl = false, e_refr = false;
@@ -699,7 +764,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       unsigned long long m1 = __ballot(e_refl), m2 = __ballot(e_refr);
       if (m1 | m2) {
         const int nl = level + 1;
-        int base = (int)cnt[nl];
+        int base = wave_uniform((int)cnt[nl]);
         int off = base + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask);
         float *qn = Q + (size_t)(nl - 2) * QFIELDS * QCAP;
         if (e_refl) {
@@ -717,9 +782,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
           qn[9 * QCAP + off] = s0; qn[10 * QCAP + off] = s1;
           qn[11 * QCAP + off] = __uint_as_float(pix | SLOT_REFRACTION);
         }
-        if (lane == 0) cnt[nl] = (unsigned)(base + __popcll(m1) + __popcll(m2));
+        const int now = base + __popcll(m1) + __popcll(m2);
+        if (lane == 0) cnt[nl] = (unsigned)now;
+        nonempty_mask |= 1u << nl;
+        if (now >= 64) full_mask |= 1u << nl;
       }
     }
+    PH_MARK(5);
+#ifdef RT_PROFILE_PHASES
+    if (n_steps == 1) ph_acc[11] = __builtin_amdgcn_s_memtime() - ph_start;
+    ph_steps += 1;
+    ph_lanes += __popcll(__ballot(active));
+#endif
   }  // scheduling loop
 
   // ---- statistics --------------------------------------------------------------------
@@ -737,8 +811,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // per-wave diagnostics (rt_wave_diag): lifetime ticks, rays processed
     P.stats[16 + gwave * 4] = life;
     P.stats[17 + gwave * 4] = n_primary + n_shadow + n_refl + n_refr;
-    P.stats[18 + gwave * 4] = wave_t0;
+    P.stats[18 + gwave * 4] = ((unsigned long long)n_steps << 40) | (wave_t0 & 0xFFFFFFFFFFull);
     P.stats[19 + gwave * 4] = t_dry - wave_t0;  // when the packet supply ran dry for this wave
+#ifdef RT_PROFILE_PHASES
+    for (int i = 0; i < 12; ++i) atomicAdd(&P.stats[65536 + 16 + i], ph_acc[i]);
+    atomicAdd(&P.stats[65536 + 16 + 12], ph_steps);
+    atomicAdd(&P.stats[65536 + 16 + 13], ph_lanes);
+#endif
   }
   if (COUNT) {
     atomicAdd(&P.stats[4], (unsigned long long)cn.box);

@@ -4,6 +4,21 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void kpk(float *out, int iters, float s) {
+  f2 a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = f2{threadIdx.x * 0.001f + i, threadIdx.x * 0.002f + i};
+  const f2 s2 = {s, s}, one = {1.0f, 1.0f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], s2, one);
+  }
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, int iters, float s) {
   float a[16];
@@ -43,6 +58,17 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   int cus = p.multiProcessorCount;
   float *d; hipMalloc(&d, (size_t)cus * 8 * 256 * 4);
+  for (int wps : {1, 2, 4, 8}) {
+    int blocks = cus * wps, iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kpk, dim3(blocks), dim3(256), 0, 0, d, iters, 0.999f);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kpk, dim3(blocks), dim3(256), 0, 0, d, iters, 0.999f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double w = (double)iters * 8 * wps;
+    printf("pk_fma     waves/SIMD %d: %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", wps, ms, ms * 1e6 / w, ms * 1e6 / w * 2.4);
+  }
   run<0>("fma", 1, d, cus);
   run<1>("mul+add", 2, d, cus);
   run<2>("cmp-select", 4, d, cus);

@@ -13,7 +13,7 @@ grids = rt.generate_grids(SEED, world.width + 10, world.camera.aa)
 r = rt.Renderer(0); r.set_world(world); r.set_samples(grids)
 buf = torch.zeros(world.height * world.width * 3 + 4096, dtype=torch.float32, device="cuda:0")
 base = None
-for n in (1, 4, 8):
+for n in (1, 8):
     for rank in ((0,) if n == 1 else (0, n - 1)):
         r.set_partition(rank, n)
         for _ in range(3):

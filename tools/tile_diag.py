@@ -3,6 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+import numpy as np
 import rt_amd as rt
 NR = int(os.environ.get("NRANKS", "1"))
 for wl in sys.argv[1:] or ["c2"]:
@@ -17,15 +18,16 @@ for wl in sys.argv[1:] or ["c2"]:
           f"waves {st.n_waves}  wave avg {st.wave_ticks_sum/max(1,st.n_waves)/100:.1f} us  "
           f"wave max {st.wave_ticks_max/100:.1f} us "
           f"rays {st.rays_total}")
-    wd = r.wave_diag(int(st.n_waves)).astype(float)
-    import numpy as np
+    wdi = r.wave_diag(int(st.n_waves))
+    steps = (wdi[:, 2] >> np.uint64(40)).astype(float)
+    wdi[:, 2] &= np.uint64((1 << 40) - 1)
+    wd = wdi.astype(float)
     life = wd[:, 0] / 100.0
     pc = np.percentile(life, [0, 10, 50, 90, 99, 100])
     top = np.argsort(life)[-3:]
     print("   wave lifetime us percentiles 0/10/50/90/99/100:", " ".join(f"{x:.0f}" for x in pc),
           " rays/wave min/med/max:", int(wd[:, 1].min()), int(np.median(wd[:, 1])), int(wd[:, 1].max()),
           " slowest waves rays:", [int(wd[i, 1]) for i in top])
-    r.close()
     t0 = wd[:, 2] - wd[:, 2].min()
     dry = (t0 + wd[:, 3]) / 100.0
     end = (t0 + wd[:, 0]) / 100.0
@@ -33,3 +35,16 @@ for wl in sys.argv[1:] or ["c2"]:
           " dry us p0/p50/p100:", " ".join(f"{x:.0f}" for x in np.percentile(dry, [0, 50, 100])),
           " end us p0/p50/p99/p100:", " ".join(f"{x:.0f}" for x in np.percentile(end, [0, 50, 99, 100])),
           " drain (end-dry) us p50/p90/p100:", " ".join(f"{x:.0f}" for x in np.percentile(end - dry, [50, 90, 100])))
+    slow = np.argsort(end)[-6:]
+    print('   slowest waves (rays, steps, dry us, end us):', [(int(wd[i,1]), int(steps[i]), int(dry[i]), int(end[i])) for i in slow],
+          ' median wave (rays, steps):', int(np.median(wd[:,1])), int(np.median(steps)))
+    ph = r.wave_diag(16384 + 4)[16384:].reshape(-1).astype(float)
+    if ph[:6].sum() > 0:
+        names = ["pop/other", "closest traversal", "shade (direct)", "shadow traversal", "accumulate", "emit bounces",
+                 "level select", "packet decode", "samples+getRay", "fetch next packet", "-", "-"]
+        print(f"   first step: wave start -> rays generated {ph[10]/st.n_waves:.0f} cycles avg, -> step done {ph[11]/st.n_waves:.0f} cycles avg")
+        ph[10] = ph[11] = 0
+        tot = ph[:12].sum()
+        print("   phases (share of summed wave cycles): " + "  ".join(f"{n} {100*v/tot:.1f}%" for n, v in zip(names, ph[:12]) if v))
+        print(f"   steps {int(ph[12])}  avg active lanes/step {ph[13]/max(1,ph[12]):.1f}  cycles/step/wave {tot/max(1,ph[12]):.0f}")
+    r.close()
