@@ -380,8 +380,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     int batches = c->batches > 0 ? c->batches : 8;
     p.batch_cap = std::min(16, std::max(1, per_shard / (waves_per_shard * batches)));
   }
-  p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 2;
-  p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 4;
+  p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 1;  // measured: 1/1 never worse on the small scenes, c3 (mesh) 28.8 -> 21.7 ms
+  p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 1;
   p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks

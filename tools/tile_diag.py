@@ -21,6 +21,10 @@ for wl in sys.argv[1:] or ["c2"]:
     wdi = r.wave_diag(int(st.n_waves))
     steps = (wdi[:, 2] >> np.uint64(40)).astype(float)
     wdi[:, 2] &= np.uint64((1 << 40) - 1)
+    given = ((wdi[:, 1] >> np.uint64(40)) & np.uint64(0xfff)).astype(int)
+    taken = (wdi[:, 1] >> np.uint64(52)).astype(int)
+    wdi[:, 1] &= np.uint64((1 << 40) - 1)
+    print(f'   work sharing: chunks given {given.sum()} taken {taken.sum()} (waves giving {np.count_nonzero(given)}, taking {np.count_nonzero(taken)})')
     wd = wdi.astype(float)
     life = wd[:, 0] / 100.0
     pc = np.percentile(life, [0, 10, 50, 90, 99, 100])
