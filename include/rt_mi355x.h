@@ -150,7 +150,8 @@ typedef struct rt_stats {
   uint64_t wave_ticks_sum;    /* diagnostics, 100 MHz ticks: sum / max of the lifetimes  */
   uint64_t wave_ticks_max;    /* of the persistent waves, and their number (load balance) */
   uint64_t n_waves;
-  double ms_kernel;           /* trace/shade kernel, HIP events on its stream */
+  double ms_kernel;           /* render_kernel alone, HIP events on its stream      */
+  double ms_launch;           /* probe + order + render + resolve kernels            */
   double ms_total;            /* whole call incl. copies                      */
 } rt_stats;
 
@@ -224,6 +225,12 @@ int rt_collect(rt_ctx *ctx, void *hip_stream, rt_stats *stats);
  * out = truncate(255 * clamp x).  n = number of floats.  Device pointers. */
 int rt_quantize_async(rt_ctx *ctx, const float *d_rgb, uint8_t *d_rgb8, size_t n,
                       void *hip_stream);
+
+/* The context's own HIP stream (a hipStream_t, created non-blocking by rt_init): what the
+ * _async calls use when hip_stream is NULL.  Two contexts on one GPU render on two hardware
+ * queues, so alternate frames overlap (the next frame's blocks fill the wave slots the
+ * current frame's tail leaves empty).  No counterpart in the reference. */
+int rt_get_stream(rt_ctx *ctx, void **hip_stream_out);
 
 /* Diagnostics of the last render, four words per persistent wave w (100 MHz ticks):
  * out[4w] lifetime, out[4w+1] rays it traversed, out[4w+2] = (scheduling steps << 40) | (start tick mod 2^40),

@@ -80,7 +80,7 @@ class Stats(C.Structure):
                 ("rays_refraction", u64), ("box_tests", u64), ("sphere_tests", u64),
                 ("triangle_tests", u64), ("primary_hits", u64), ("shaded_hits", u64),
                 ("wave_ticks_sum", u64), ("wave_ticks_max", u64), ("n_waves", u64),
-                ("ms_kernel", C.c_double), ("ms_total", C.c_double)]
+                ("ms_kernel", C.c_double), ("ms_launch", C.c_double), ("ms_total", C.c_double)]
 
     @property
     def rays_total(self) -> int:
@@ -114,7 +114,7 @@ DEVICE_SYMBOLS = [
     "rt_init", "rt_shutdown", "rt_upload_scene", "rt_set_camera", "rt_set_samples",
     "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
-    "rt_wave_diag",
+    "rt_wave_diag", "rt_get_stream",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_build_bvh",
@@ -216,6 +216,7 @@ def device_lib() -> C.CDLL:
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
         L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
         L.rt_wave_diag.argtypes = [vp, C.POINTER(u64), i32]
+        L.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
         L.rt_abi_version.restype = C.c_int
@@ -475,6 +476,13 @@ class Renderer:
         st = Stats()
         self._check(self.lib.rt_collect(self._h, stream or None, C.byref(st)), "rt_collect")
         return st
+
+    @property
+    def stream(self) -> int:
+        """The context's own hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._check(self.lib.rt_get_stream(self._h, C.byref(p)), "rt_get_stream")
+        return p.value or 0
 
     def wave_diag(self, n_waves: int) -> np.ndarray:
         """[n_waves, 4] (lifetime ticks @100 MHz, rays, start tick, dry tick) of the last render."""

@@ -20,7 +20,7 @@ struct rt_ctx {
   int device = 0;
   int n_cus = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
   bool timed = false;
   std::string err;
 
@@ -345,6 +345,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   LaunchCfg cfg{};
   cfg.block = 64 * WAVES_PER_BLOCK;
   cfg.lds_bytes = lds_bytes_for(c->stack_depth);
+  cfg.ev_k0 = c->evk0;
+  cfg.ev_k1 = c->evk1;
   cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
   cfg.count = (flags & RT_FLAG_COUNT_TESTS) != 0;
   // Small scenes (every shipped benchmark scene but bench3) are staged into each block's LDS:
@@ -425,6 +427,8 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   if (c->timed) {
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st->ms_launch = ms;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->evk0, c->evk1));
     st->ms_kernel = ms;
   }
   return RT_OK;
@@ -457,6 +461,7 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
             hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 16) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
@@ -478,6 +483,8 @@ void rt_shutdown(rt_ctx *c) {
     if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->evk0) (void)hipEventDestroy(c->evk0);
+  if (c->evk1) (void)hipEventDestroy(c->evk1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -618,6 +625,12 @@ int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, 
   int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, s, d_rgb, d_rgb8, n);
   HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_get_stream(rt_ctx *c, void **out) {
+  if (!c || !out) return RT_ERR_INVALID;
+  *out = (void *)c->stream;
   return RT_OK;
 }
 

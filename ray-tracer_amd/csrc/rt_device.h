@@ -85,6 +85,7 @@ struct LaunchCfg {
   int grid, block;
   size_t lds_bytes;
   bool prune, count;
+  hipEvent_t ev_k0, ev_k1;  // recorded right before / after render_kernel (may be null)
   bool lds_scene;           // render from the block's LDS copy of the scene
   size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
 };

@@ -1012,6 +1012,7 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
       hipLaunchKernelGGL((probe_kernel<false>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
     hipLaunchKernelGGL(order_kernel, dim3(p.probe_blocks), dim3(256), 0, s, p);
   }
+  if (cfg.ev_k0) (void)hipEventRecord(cfg.ev_k0, s);  // around the trace/shade kernel alone
   if (cfg.prune) {
     if (cfg.count) launch_t<true, true>(p, cfg, s);
     else launch_t<true, false>(p, cfg, s);
@@ -1019,6 +1020,7 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
     if (cfg.count) launch_t<false, true>(p, cfg, s);
     else launch_t<false, false>(p, cfg, s);
   }
+  if (cfg.ev_k1) (void)hipEventRecord(cfg.ev_k1, s);
   size_t total = (size_t)p.n_local_tiles * p.tile_w * p.tile_h;
   if (total) {
     int grid = (int)((total + 255) / 256);

@@ -7,9 +7,10 @@ into a compact buffer [n_local_tiles][tile_h][tile_w][3]; the ONE exchange step 
 path is the gather of those buffers on rank 0 (RCCL over xGMI when the process group's
 backend is "nccl"), followed by rt_assemble_async, which scatters them into the frame.
 
-Frames are pipelined: the gather of frame k runs on the collective's stream while the
-trace/shade kernel of frame k+1 runs on the render stream (double-buffered tile
-buffers), so at N ranks the per-frame cost is max(render/N, gather) rather than their sum.
+Frames are pipelined: `in_flight` contexts (rt_ctx) render alternate frames on their own
+streams, so the kernel of frame k+1 overlaps both the tail of frame k's kernel and its
+gather (which runs on the collective's stream); at N ranks the per-frame cost tends to
+max(average wave time, gather) rather than slowest wave + gather.
 
 torch is used for device memory, streams and torch.distributed only.
 """
@@ -44,24 +45,35 @@ def gather_tiles(mine: torch.Tensor, gathered: Optional[torch.Tensor], dst: int 
 class DistributedFrame:
     """One rank's side of the tiled, gathered, pipelined frame render.
 
-    renderer: an rt.Renderer with world and samples already set, on `device`.
-    After `finish()`, rank 0 holds the newest frame in `self.frame` ([H*W*3] float32,
+    make_renderer: callable returning an rt.Renderer (one rt_ctx) with world and samples set,
+    on `device`.  `in_flight` contexts render alternate frames on their own streams: a
+    context owns every per-frame buffer (pixel sums, ray queues, ticket counters), so frame
+    k+1's kernel may start while frame k's is still running, and the hardware places its
+    blocks into the wave slots that frame k's tail (a few deep ray trees) leaves empty.
+    After `finish()`, rank 0 holds the newest frames in `self.frames` ([H*W*3] float32 each,
     render's pixel order)."""
 
-    def __init__(self, renderer, rank: int, nranks: int, device: torch.device, pipeline: int = 2):
-        self.r, self.rank, self.nranks, self.device = renderer, rank, nranks, device
-        renderer.set_partition(rank, nranks)
-        til = renderer.tiling()
+    def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 2):
+        self.rank, self.nranks, self.device = rank, nranks, device
+        self.depth = max(1, in_flight)
+        self.renderers = [make_renderer() for _ in range(self.depth)]
+        for r in self.renderers:
+            r.set_partition(rank, nranks)
+        self.r = self.renderers[0]
+        til = self.r.tiling()
         self.tile_floats, self.stride = partition_layout(til.n_tiles, til.tile_w, til.tile_h, nranks)
-        w = renderer.world
+        w = self.r.world
         self.is_root = rank == 0
-        self.frame = torch.zeros(w.height * w.width * 3, dtype=torch.float32, device=device) \
-            if self.is_root else None
-        self.render_stream = torch.cuda.Stream(device=device)
+        self.frames = [torch.zeros(w.height * w.width * 3, dtype=torch.float32, device=device)
+                       for _ in range(self.depth)] if self.is_root else [None] * self.depth
+        # every context renders on ITS OWN stream (created by rt_init, one hardware queue each);
+        # torch only wraps it, so that events and the collective's stream can be ordered
+        # against it.  (Two streams from torch's pool were measured to land on one hardware
+        # queue: no overlap at all.)
+        self.streams = [torch.cuda.ExternalStream(r.stream, device=device) for r in self.renderers]
         self.k = 0
         if nranks == 1:
             return
-        self.depth = max(1, pipeline)
         self.mine = [torch.zeros(self.stride, dtype=torch.float32, device=device)
                      for _ in range(self.depth)]
         self.gathered = [torch.zeros(nranks * self.stride, dtype=torch.float32, device=device)
@@ -70,27 +82,32 @@ class DistributedFrame:
         self.asm_stream = torch.cuda.Stream(device=device)
         self.asm_done = [None] * self.depth
 
+    @property
+    def frame(self):
+        """The most recently submitted frame (valid after finish())."""
+        return self.frames[(self.k - 1) % self.depth] if self.k else self.frames[0]
+
     def submit(self, flags: int = 0) -> None:
         """Enqueue one frame; returns without waiting for the GPU."""
-        rs = self.render_stream
+        slot = self.k % self.depth
+        rs, r = self.streams[slot], self.renderers[slot]
         if self.nranks == 1:
-            self.r.render_async(self.frame.data_ptr(), 0, flags, rs.cuda_stream)
+            r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
             self.k += 1
             return
-        slot = self.k % self.depth
         with torch.cuda.stream(rs):
             if self.works[slot] is not None:
                 self.works[slot].wait()          # mine[slot] is free once its gather is done
             if self.asm_done[slot] is not None:
-                rs.wait_event(self.asm_done[slot])  # gathered[slot] is free once assembled
-            self.r.render_tiles_async(self.mine[slot].data_ptr(), flags, rs.cuda_stream)
+                rs.wait_event(self.asm_done[slot])  # gathered[slot]/frames[slot] free once assembled
+            r.render_tiles_async(self.mine[slot].data_ptr(), flags, rs.cuda_stream)
             # the collective's stream picks up after the kernel just enqueued on rs
             self.works[slot] = gather_tiles(self.mine[slot], self.gathered[slot], 0, async_op=True)
         if self.is_root:
             with torch.cuda.stream(self.asm_stream):
                 self.works[slot].wait()
-                self.r.assemble_async(self.gathered[slot].data_ptr(), self.nranks, self.stride,
-                                      self.frame.data_ptr(), self.asm_stream.cuda_stream)
+                r.assemble_async(self.gathered[slot].data_ptr(), self.nranks, self.stride,
+                                 self.frames[slot].data_ptr(), self.asm_stream.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(self.asm_stream)
                 self.asm_done[slot] = ev
@@ -103,3 +120,7 @@ class DistributedFrame:
                 if w is not None:
                     w.wait()
         torch.cuda.synchronize(self.device)
+
+    def close(self) -> None:
+        for r in self.renderers:
+            r.close()

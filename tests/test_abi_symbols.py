@@ -47,7 +47,7 @@ def test_pod_sizes_match_the_header(rt):
     assert C.sizeof(rt.Material) == 48
     assert C.sizeof(rt.Light) == 48
     assert C.sizeof(rt.Camera) == 4 * (2 + 3 + 1 + 1 + 6 + 9 + 3 + 1)
-    assert C.sizeof(rt.Stats) == 12 * 8 + 2 * 8
+    assert C.sizeof(rt.Stats) == 12 * 8 + 3 * 8
 
 
 def test_render_without_gpu_fails_loudly(rt):

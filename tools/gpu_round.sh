@@ -8,5 +8,5 @@ tail -3 gpurun_out/gpu_tests.log
 timeout -k 10 300 python bench.py > gpurun_out/bench.log 2>&1 || { echo "bench FAILED"; tail -20 gpurun_out/bench.log; exit 1; }
 tail -1 gpurun_out/bench.log
 rm -rf gpurun_out/prof_stats
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1 || { echo "rocprof FAILED"; tail -20 gpurun_out/prof_stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > gpurun_out/prof_stats.log 2>&1 || { echo "rocprof FAILED"; tail -20 gpurun_out/prof_stats.log; exit 1; }
 find gpurun_out/prof_stats -name '*kernel_stats.csv' -exec cat {} \;

@@ -21,7 +21,7 @@ for n in (1, 8):
         ts = []
         for _ in range(8):
             t0 = time.perf_counter(); r.render_tiles_async(buf.data_ptr()); st = r.collect(); ts.append((time.perf_counter() - t0) * 1e3)
-        ms = st.ms_kernel
+        ms = st.ms_launch
         if base is None: base = ms
         print(f"{wl} N={n} rank={rank}: launch {ms:.3f} ms (host wall {min(ts):.3f}) rays {st.rays_total}  eff {base / (n * ms):.3f}", flush=True)
 r.close()

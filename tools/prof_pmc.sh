@@ -4,7 +4,7 @@
 # One rocprofv3 run per pass (counters do not split over passes; see the environment notes).
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline"}
+ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 pass() {
