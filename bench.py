@@ -70,6 +70,24 @@ def algorithmic_flops(st) -> float:
             + 140.0 * st.shaded_hits + 40.0 * st.rays_shadow)
 
 
+def pmc_traffic(workload: str):
+    """HBM bytes per launch of render_kernel from the committed PMC pass (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, tools/prof_pmc.sh -> profiles/): counters
+    cannot be read inside this process.  FETCH_SIZE (KB) is doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 (it tallies 128-B requests at 64 B); WRITE_SIZE (KB) is exact."""
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc.txt")
+    if not os.path.exists(path):
+        return None, None
+    vals = {}
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 3 and f[-1].startswith("avg="):
+            vals[f[0]] = float(f[-1][4:])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(world, grids, seconds_target: float = 25.0):
     """Time the CPU restatement (oracle, kind 'port') single-threaded -- the reference's
     render is a sequential map -- on stripes of rows of the SAME frame."""
@@ -198,9 +216,11 @@ def main() -> None:
         tf = flops / (kernel_ms * 1e-3) / 1e12
         gbps = rays_frame * BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
         out["config"]["frame_latency_ms"] = round(float(np.mean(lms)), 4)
+        traffic, traffic_src = pmc_traffic(args.workload)
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(tf, 3), "peak": PEAK_VALU_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_how": "HIP events around render_kernel on its launch stream, 1 frame in flight, "
                              f"mean of {args.steps} launches",

@@ -46,6 +46,16 @@ rth_scene *rth_scene_create(const rt_sphere *spheres, int32_t n_spheres,
                             const rt_light *lights, int32_t n_lights);
 void rth_scene_free(rth_scene *s);
 
+/* parseObj + convertMesh + fromMesh (src/HaObj.hs:63-130, src/Convert.hs:15-78): the objects
+ * of a .obj/.mtl pair in the reference's dialect, in the reference's [Object] order (groups
+ * with `s off`/0 first, then smooth groups; one material per usemtl group; degenerate faces
+ * dropped; flat normals).  No lights.  On failure returns NULL and writes the reason
+ * (parse error, unknown material, non-triangle face, invalid illum) to err. */
+rth_scene *rth_scene_load_obj(const char *obj_path, char *err, size_t err_len);
+int rth_scene_add_light(rth_scene *s, const rt_light *light);
+/* the eight point lights of bench6World (src/Main.hs:239-246) */
+int rth_scene_add_bench6_lights(rth_scene *s);
+
 /* Build the tree.  builder 0 = sahBVH (BoundingVolumeHierarchy.hs:34-51),
  * 1 = noBVH (one leaf with every object, BoundingVolumeHierarchy.hs:130-131). */
 int rth_scene_build_bvh(rth_scene *s, int builder);

@@ -117,7 +117,8 @@ DEVICE_SYMBOLS = [
     "rt_wave_diag", "rt_get_stream",
 ]
 HOST_SYMBOLS = [
-    "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_build_bvh",
+    "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
+    "rth_scene_add_light", "rth_scene_add_bench6_lights", "rth_scene_build_bvh",
     "rth_scene_view", "rth_scene_n_objects", "rth_scene_bvh_depth", "rth_default_config",
     "rth_config_to_camera", "rth_generate_grids", "rth_write_ppm", "rth_quantize",
     "rth_material_by_name", "rth_make_triangle",
@@ -148,6 +149,10 @@ def host_lib() -> C.CDLL:
         L.rth_scene_create.argtypes = [C.POINTER(Sphere), i32, C.POINTER(Triangle), i32,
                                        C.POINTER(u32), i32, C.POINTER(Material), i32,
                                        C.POINTER(Light), i32]
+        L.rth_scene_load_obj.restype = C.c_void_p
+        L.rth_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.rth_scene_add_light.argtypes = [C.c_void_p, C.POINTER(Light)]
+        L.rth_scene_add_bench6_lights.argtypes = [C.c_void_p]
         L.rth_scene_free.argtypes = [C.c_void_p]
         L.rth_scene_free.restype = None
         L.rth_scene_build_bvh.argtypes = [C.c_void_p, C.c_int]
@@ -286,6 +291,23 @@ class Scene:
         la = (Light * max(1, len(lights)))(*lights)
         s = cls(host_lib().rth_scene_create(sa, len(spheres), ta, len(triangles), oa, len(order),
                                             ma, len(materials), la, len(lights)))
+        s.build_bvh(bvh)
+        return s
+
+    @classmethod
+    def from_obj(cls, path: str, lights: Optional[Sequence[Light]] = None, bvh: str = "sah") -> "Scene":
+        """parseObj + convertMesh + fromMesh (HaObj.hs:63, Convert.hs:15-39).  `lights`
+        None = the eight point lights of bench6World (Main.hs:239-246)."""
+        err = C.create_string_buffer(512)
+        h = host_lib().rth_scene_load_obj(path.encode(), err, 512)
+        if not h:
+            raise RtError(f"cannot load {path}: {err.value.decode()}")
+        s = cls(h)
+        if lights is None:
+            host_lib().rth_scene_add_bench6_lights(s._h)
+        else:
+            for l in lights:
+                host_lib().rth_scene_add_light(s._h, C.byref(l))
         s.build_bvh(bvh)
         return s
 

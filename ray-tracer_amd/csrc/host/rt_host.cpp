@@ -7,11 +7,15 @@
 #include "rt_host.h"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <limits>
+#include <map>
+#include <sstream>
 #include <random>
 #include <string>
 #include <vector>
@@ -564,6 +568,219 @@ void build_mesh(rth_scene &s, int target_tris) {
   mesh_floor(s, O, -3, 16, nf, m_fa, m_fb);
 }
 
+
+// --------------------------------------------------------- .obj / .mtl import
+// HaObj.hs (grammar) + Convert.hs (Mesh -> [Object]).  Line oriented, same dialect:
+//   .obj : comments / blank lines, `mtllib <file>`, then objects `o <name>` each made of
+//          `v x y z`*, `vt ..`*, `vn x y z`*, `vp ..`*, groups (`usemtl <name>`, optional
+//          `s off|<n>`, `f i[/t][/n] j.. k..`+), `l a b`*          (HaObj.hs:76-130)
+//   .mtl : `newmtl <name>`, `Ns`, `Ka`, `Kd`, `Ks`, optional `Ni` (default 1.0), `d`,
+//          `illum`                                                  (HaObj.hs:148-162)
+// makeScene (HaObj.hs:44-54): vertex indices are global over the file (1-based); the
+// groups with s == 0 come first, then the smooth ones, each in file order.  convertMesh
+// (Convert.hs:29-39) gives every GROUP its own material index; fromMesh (Convert.hs:15-27)
+// drops faces with two equal corners or a NaN normal and uses the flat calcNormal.
+struct ObjError {
+  std::string msg;
+};
+
+struct MtlEntry {
+  float ns = 0, ka[3] = {0, 0, 0}, kd[3] = {0, 0, 0}, ks[3] = {0, 0, 0}, ni = 1.0f, d = 1.0f;
+  int illum = -1;
+};
+
+// convertMaterial (Convert.hs:55-78), all eleven illumination models.
+rt_material convert_material(const MtlEntry &m) {
+  const float xx[3] = {0, 0, 0}, white[3] = {1, 1, 1}, opaque[3] = {99, 99, 99};
+  const float phong = (m.ns == 0) ? 10.0f : m.ns * 10;
+  const float refr = m.ni;
+  switch (m.illum) {
+    case 0:
+    case 1: return make_material(m.kd, xx, 0, 0, 0, xx);
+    case 2: return make_material(m.kd, m.ks, phong, 0, 0, xx);
+    case 3: return make_material(m.kd, m.ks, phong, 1, 0, opaque);
+    case 4: return make_material(m.kd, m.ks, phong, 0, refr, white);
+    case 5: return make_material(m.kd, m.ks, phong, 1, 0, opaque);
+    case 6:
+    case 7:
+    case 8: return make_material(m.kd, m.ks, phong, 1, refr, opaque);
+    case 9: return make_material(xx, white, phong, 1, refr, white);
+    case 10: return make_material(m.kd, m.ks, phong, 0, 0, xx);
+    default: throw ObjError{"invalid illum value " + std::to_string(m.illum)};
+  }
+}
+
+std::vector<std::string> split_ws(const std::string &line) {
+  std::vector<std::string> out;
+  std::istringstream is(line);
+  std::string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+
+// `float` of HaObj.hs:212-215: [+-]digits[.digits][(e|E)[+-]digits]
+float parse_float(const std::string &t, const std::string &where) {
+  size_t i = 0, n = t.size();
+  auto digits = [&]() { size_t k = i; while (i < n && std::isdigit((unsigned char)t[i])) ++i; return i > k; };
+  if (i < n && (t[i] == '+' || t[i] == '-')) ++i;
+  bool ok = digits();
+  if (ok && i < n && t[i] == '.') { ++i; ok = digits(); }
+  if (ok && i < n && (t[i] == 'e' || t[i] == 'E')) {
+    ++i;
+    if (i < n && (t[i] == '+' || t[i] == '-')) ++i;
+    ok = digits();
+  }
+  if (!ok || i != n) throw ObjError{where + ": bad number '" + t + "'"};
+  return strtof(t.c_str(), nullptr);
+}
+int parse_uint(const std::string &t, const std::string &where) {
+  if (t.empty() || t.size() > 9) throw ObjError{where + ": bad index '" + t + "'"};
+  for (char c : t)
+    if (!std::isdigit((unsigned char)c)) throw ObjError{where + ": bad index '" + t + "'"};
+  return std::atoi(t.c_str());
+}
+void parse_v3(const std::vector<std::string> &tok, float out[3], const std::string &where) {
+  if (tok.size() != 4) throw ObjError{where + ": unexpected number of floats"};
+  for (int i = 0; i < 3; ++i) out[i] = parse_float(tok[1 + i], where);
+}
+
+std::map<std::string, MtlEntry> read_mtl(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw ObjError{"cannot open material library '" + path + "'"};
+  std::map<std::string, MtlEntry> out;
+  std::string line, name;
+  MtlEntry cur;
+  int have = 0, ln = 0;  // bits: Ns Ka Kd Ks d illum
+  auto flush = [&]() {
+    if (name.empty()) return;
+    if ((have & 0x3f) != 0x3f) throw ObjError{path + ": material '" + name + "' is missing Ns/Ka/Kd/Ks/d/illum"};
+    if (!out.count(name)) out[name] = cur;  // Data.Map.fromList keeps the LAST duplicate ...
+    else out[name] = cur;                   // ... so later definitions replace earlier ones
+  };
+  while (std::getline(f, line)) {
+    ++ln;
+    const std::string where = path + ":" + std::to_string(ln);
+    std::vector<std::string> tok = split_ws(line);
+    if (tok.empty() || tok[0][0] == '#') continue;
+    if (tok[0] == "newmtl") {
+      flush();
+      size_t at = line.find("newmtl") + 6;
+      while (at < line.size() && std::isspace((unsigned char)line[at])) ++at;
+      name = line.substr(at);
+      while (!name.empty() && (name.back() == '\r' || name.back() == '\n')) name.pop_back();
+      cur = MtlEntry();
+      have = 0;
+    } else if (name.empty()) {
+      throw ObjError{where + ": expected newmtl"};
+    } else if (tok[0] == "Ns" && tok.size() == 2) { cur.ns = parse_float(tok[1], where); have |= 1; }
+    else if (tok[0] == "Ka") { parse_v3(tok, cur.ka, where); have |= 2; }
+    else if (tok[0] == "Kd") { parse_v3(tok, cur.kd, where); have |= 4; }
+    else if (tok[0] == "Ks") { parse_v3(tok, cur.ks, where); have |= 8; }
+    else if (tok[0] == "Ni" && tok.size() == 2) { cur.ni = parse_float(tok[1], where); }
+    else if (tok[0] == "d" && tok.size() == 2) { cur.d = parse_float(tok[1], where); have |= 16; }
+    else if (tok[0] == "illum" && tok.size() == 2) { cur.illum = parse_uint(tok[1], where); have |= 32; }
+    else throw ObjError{where + ": unexpected '" + tok[0] + "'"};
+  }
+  flush();
+  return out;
+}
+
+struct FaceGroup {
+  std::string mtl;
+  int smooth = 0;
+  std::vector<int> corners;  // 3 vertex indices (1-based) per face
+};
+
+rth_scene *load_obj(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw ObjError{"cannot open '" + path + "'"};
+  std::vector<float> verts;  // global vertex list (concat vs)
+  std::vector<FaceGroup> groups;
+  std::string line, mtllib;
+  bool in_object = false, group_open = false;
+  int ln = 0;
+  while (std::getline(f, line)) {
+    ++ln;
+    const std::string where = path + ":" + std::to_string(ln);
+    std::vector<std::string> tok = split_ws(line);
+    if (tok.empty() || tok[0][0] == '#') continue;
+    if (mtllib.empty()) {
+      if (tok[0] != "mtllib" || tok.size() < 2) throw ObjError{where + ": expected mtllib (HaObj.hs:78)"};
+      size_t at = line.find("mtllib") + 6;
+      while (at < line.size() && std::isspace((unsigned char)line[at])) ++at;
+      mtllib = line.substr(at);
+      while (!mtllib.empty() && std::isspace((unsigned char)mtllib.back())) mtllib.pop_back();
+      continue;
+    }
+    if (tok[0] == "o") { in_object = true; group_open = false; continue; }
+    if (!in_object) throw ObjError{where + ": expected 'o <name>' (HaObj.hs:83)"};
+    if (tok[0] == "v") {
+      float v[3];
+      parse_v3(tok, v, where);
+      verts.insert(verts.end(), v, v + 3);
+    } else if (tok[0] == "vn" || tok[0] == "vt" || tok[0] == "vp") {
+      for (size_t i = 1; i < tok.size(); ++i) parse_float(tok[i], where);  // parsed, unused (Convert.hs:11)
+    } else if (tok[0] == "usemtl") {
+      size_t at = line.find("usemtl") + 6;
+      while (at < line.size() && std::isspace((unsigned char)line[at])) ++at;
+      FaceGroup g;
+      g.mtl = line.substr(at);
+      while (!g.mtl.empty() && std::isspace((unsigned char)g.mtl.back())) g.mtl.pop_back();
+      groups.push_back(g);
+      group_open = true;
+    } else if (tok[0] == "s") {
+      if (!group_open || !groups.back().corners.empty() || tok.size() != 2)
+        throw ObjError{where + ": 's' must follow usemtl (HaObj.hs:112)"};
+      groups.back().smooth = (tok[1] == "off") ? 0 : parse_uint(tok[1], where);
+    } else if (tok[0] == "f") {
+      if (!group_open) throw ObjError{where + ": face before usemtl (HaObj.hs:110-115)"};
+      if (tok.size() != 4) throw ObjError{where + ": non-triangle face " + std::to_string(tok.size() - 1)};  // Convert.hs:50
+      for (int i = 1; i <= 3; ++i) {
+        std::string c = tok[i].substr(0, tok[i].find('/'));  // v[/vt][/vn] or v//vn: only v is used
+        groups.back().corners.push_back(parse_uint(c, where));
+      }
+    } else if (tok[0] == "l") {
+      // lines are parsed and ignored (HaObj.hs:100-105)
+    } else {
+      throw ObjError{where + ": unexpected '" + tok[0] + "'"};
+    }
+  }
+  if (mtllib.empty()) throw ObjError{path + ": no mtllib"};
+  // the reference opens mtllib relative to the working directory; fall back to the .obj's
+  std::string mpath = mtllib;
+  if (!std::ifstream(mpath)) {
+    size_t slash = path.find_last_of('/');
+    if (slash != std::string::npos) mpath = path.substr(0, slash + 1) + mtllib;
+  }
+  std::map<std::string, MtlEntry> mtls = read_mtl(mpath);
+  for (const FaceGroup &g : groups)
+    if (g.corners.empty()) throw ObjError{path + ": usemtl '" + g.mtl + "' without faces (many1 ngonFace)"};
+
+  rth_scene *s = new rth_scene();
+  try {
+    const int nv = (int)(verts.size() / 3);
+    int group_index = 0;
+    for (int pass = 0; pass < 2; ++pass)          // partition: s == 0 first, then smooth
+      for (const FaceGroup &g : groups) {
+        if ((g.smooth == 0) != (pass == 0)) continue;
+        auto it = mtls.find(g.mtl);
+        if (it == mtls.end()) throw ObjError{"\"" + g.mtl + "\" not found"};  // findMaterial
+        int mi = s->material(convert_material(it->second), "group" + std::to_string(group_index++));
+        for (size_t k = 0; k + 2 < g.corners.size(); k += 3) {
+          int ix[3] = {g.corners[k] - 1, g.corners[k + 1] - 1, g.corners[k + 2] - 1};  // convertFaceV
+          for (int q : ix)
+            if (q < 0 || q >= nv) throw ObjError{path + ": vertex index " + std::to_string(q + 1) + " out of range"};
+          V3 a = get(&verts[3 * ix[0]]), b = get(&verts[3 * ix[1]]), c = get(&verts[3 * ix[2]]);
+          s->mesh_triangle(a, b, c, mi);  // drops degenerate faces (Convert.hs:20)
+        }
+      }
+  } catch (...) {
+    delete s;
+    throw;
+  }
+  return s;
+}
+
 const struct {
   const char *name;
   rth_config cfg;
@@ -655,6 +872,33 @@ rth_scene *rth_scene_create(const rt_sphere *spheres, int32_t n_spheres,
 }
 
 void rth_scene_free(rth_scene *s) { delete s; }
+
+rth_scene *rth_scene_load_obj(const char *obj_path, char *err, size_t err_len) {
+  if (err && err_len) err[0] = 0;
+  if (!obj_path) return nullptr;
+  try {
+    return load_obj(obj_path);
+  } catch (const ObjError &e) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", e.msg.c_str());
+  } catch (const std::exception &e) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+  }
+  return nullptr;
+}
+
+int rth_scene_add_light(rth_scene *s, const rt_light *light) {
+  if (!s || !light) return RT_ERR_INVALID;
+  s->lights.push_back(*light);
+  return RT_OK;
+}
+
+int rth_scene_add_bench6_lights(rth_scene *s) {  // bench6World, Main.hs:239-246
+  if (!s) return RT_ERR_INVALID;
+  const float lp[8][3] = {{10, 20, 0},  {-10, 20, 0},  {0, 20, 10},  {0, 20, -10},
+                          {0, -20, 10}, {0, -20, -10}, {10, -20, 0}, {-10, -20, 0}};
+  for (int i = 0; i < 8; ++i) s->light(get(lp[i]), v3(0, 0, 0), v3(0, 0, 0), v3(0.5f, 0.5f, 0.5f));
+  return RT_OK;
+}
 
 int rth_scene_build_bvh(rth_scene *s, int builder) {
   if (!s) return RT_ERR_INVALID;

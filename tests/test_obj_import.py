@@ -1,0 +1,179 @@
+"""`.obj` / `.mtl` ingest: rth_scene_load_obj against the reference's
+grammar (src/HaObj.hs:76-215) and conversion rules (src/Convert.hs:15-78).  CPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+MTL = """# materials
+newmtl shiny
+Ns 5.0
+Ka 0.1 0.1 0.1
+Kd 0.5 0.25 0.125
+Ks 1.0 1.0 1.0
+Ni 1.5
+d 1.0
+illum 6
+
+newmtl flat
+Ns 0
+Ka 0 0 0
+Kd 0.2 0.4 0.6
+Ks 0.3 0.3 0.3
+d 1.0
+illum 2
+newmtl plain
+Ns 7
+Ka 0 0 0
+Kd 1 0 0
+Ks 1 1 1
+d 1
+illum 1
+"""
+
+OBJ = """# two objects, global vertex numbering
+mtllib scene.mtl
+o first
+v 0 0 0
+v 1 0 0
+v 0 1 0
+v 0 0 1
+vn 0 0 1
+usemtl shiny
+s 1
+f 1 2 3
+f 1//1 3//1 4//1
+usemtl flat
+s off
+f 2 3 4
+f 2 2 4
+o second
+v 5.5 0 0
+v 5.5 1e0 0
+v 5.5 0 -2.5E-1
+usemtl plain
+f 5/1/1 6/2/1 7/3/1
+l 1 2
+"""
+
+
+def write_pair(tmp_path, obj=OBJ, mtl=MTL):
+    p = os.path.join(tmp_path, "scene.obj")
+    open(p, "w").write(obj)
+    open(os.path.join(tmp_path, "scene.mtl"), "w").write(mtl)
+    return p
+
+
+def tris(scene):
+    v = scene.view
+    out = []
+    for i in range(v.n_triangles):
+        t = v.triangles[i]
+        out.append([list(t.a), list(t.b), list(t.c), list(t.n), t.material, t.object_id])
+    return out
+
+
+def test_load_obj_order_materials_and_degenerates(rt, tmp_path):
+    s = rt.Scene.from_obj(write_pair(tmp_path))
+    t = tris(s)
+    # makeScene (HaObj.hs:51): groups with s == 0 first (flat, plain), then the smooth one (shiny);
+    # the degenerate face `2 2 4` is dropped (Convert.hs:20)
+    assert len(t) == 4 and s.n_objects == 4 and s.view.n_spheres == 0
+    assert [x[5] for x in t] == [0, 1, 2, 3]
+    assert t[0][0:3] == [[1, 0, 0], [0, 1, 0], [0, 0, 1]]            # flat: f 2 3 4
+    assert t[1][0:3] == [[5.5, 0, 0], [5.5, 1, 0], [5.5, 0, -0.25]]  # plain (second object, global indices)
+    assert t[2][0:3] == [[0, 0, 0], [1, 0, 0], [0, 1, 0]]            # shiny: f 1 2 3
+    assert t[3][0:3] == [[0, 0, 0], [0, 1, 0], [0, 0, 1]]
+    # flat normals by calcNormal (Objects.hs:13-15); `vn` is parsed and ignored (Convert.hs:11)
+    n = 1 / math.sqrt(3)
+    assert np.allclose(t[0][3], [n, n, n], rtol=1e-6) and t[2][3] == [0, 0, 1]
+    # one material per usemtl group, in group order (Convert.hs:33)
+    assert [x[4] for x in t] == [0, 1, 2, 2] and s.view.n_materials == 3
+    m = s.view.materials
+    flat, plain, shiny = m[0], m[1], m[2]
+    # illum 2: makeMaterial dC sC phong 0 0 xx; Ns == 0 -> phong 10 (Convert.hs:60,77)
+    assert list(flat.diffuse) == pytest.approx([0.2, 0.4, 0.6]) and flat.phong == 10.0
+    assert flat.refl == 0 and flat.refr_ix == 0 and list(flat.log_atten) == [-math.inf] * 3
+    # illum 1: specular black, phong 0 (Convert.hs:59)
+    assert list(plain.specular) == [0, 0, 0] and plain.phong == 0 and plain.refl == 0
+    # illum 6: reflection 1, refraction Ni, phong Ns*10, attenuation opaque = log 99 (Convert.hs:64)
+    assert shiny.phong == 50.0 and shiny.refl == 1.0 and shiny.refr_ix == 1.5
+    assert shiny.log_atten[0] == pytest.approx(math.log(99), rel=1e-6)
+    # lights of bench6World (Main.hs:239-246)
+    assert s.view.n_lights == 8 and list(s.view.lights[1].corner) == [-10, 20, 0]
+    assert list(s.view.lights[0].edge_a) == [0, 0, 0] and list(s.view.lights[7].color) == [0.5] * 3
+    assert len(s.nodes()) >= 1   # sahBVH built
+
+
+@pytest.mark.parametrize("obj,mtl,needle", [
+    (OBJ.replace("f 2 3 4\n", "f 1 2 3 4\n"), MTL, "non-triangle face 4"),        # Convert.hs:50
+    (OBJ.replace("usemtl flat", "usemtl nosuch"), MTL, "not found"),               # HaObj.hs:57
+    (OBJ, MTL.replace("illum 6", "illum 11"), "invalid illum value 11"),          # Convert.hs:69
+    (OBJ.replace("mtllib scene.mtl\n", ""), MTL, "expected mtllib"),               # HaObj.hs:78
+    (OBJ.replace("f 2 3 4\n", "f 2 3 99\n"), MTL, "out of range"),
+    (OBJ.replace("v 1 0 0\n", "v 1 0\n"), MTL, "unexpected number of floats"),     # HaObj.hs:182
+    (OBJ, MTL.replace("Kd 0.2 0.4 0.6\n", ""), "missing"),
+])
+def test_load_obj_errors(rt, tmp_path, obj, mtl, needle):
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene.from_obj(write_pair(tmp_path, obj, mtl))
+    assert needle in str(e.value)
+
+
+def fmt(x):
+    return np.format_float_positional(np.float32(x), unique=True, trim="0")
+
+
+# the .mtl that build_mesh's materials correspond to (ray-tracer_amd/csrc/host/rt_host.cpp)
+MESH_MTL = {
+    0: ("hub", 3, (0.6, 0.6, 0.65), (1, 1, 1), 100, 1),
+    1: ("ring", 3, (1, 0.842, 0.1), (1, 0.842, 0.1), 50, 1),
+    2: ("pod", 6, (0, 0, 0), (1, 1, 1), 1000, 1.5),
+    3: ("pod2", 4, (0.2, 0.3, 0.9), (1, 1, 1), 100, 1.3),
+    4: ("spoke", 2, (0.9, 0.15, 0.1), (0.5, 0.5, 0.5), 10, 1),
+    5: ("floor_a", 2, (1, 1, 1), (0.5, 0.5, 0.5), 5, 1),
+    6: ("floor_b", 2, (0.15, 0.15, 0.2), (0.5, 0.5, 0.5), 5, 1),
+}
+
+
+def dump_obj(scene, path):
+    """Write a triangle scene in the HaObj dialect: one object, consecutive faces of one
+    material form one usemtl group."""
+    v = scene.view
+    with open(path[:-4] + ".mtl", "w") as f:
+        for name, illum, kd, ks, ns, ni in MESH_MTL.values():
+            f.write(f"newmtl {name}\nNs {fmt(ns)}\nKa 0 0 0\nKd {' '.join(map(fmt, kd))}\n"
+                    f"Ks {' '.join(map(fmt, ks))}\nNi {fmt(ni)}\nd 1\nillum {illum}\n\n")
+    with open(path, "w") as f:
+        f.write(f"# generated\nmtllib {os.path.basename(path)[:-4]}.mtl\no station\n")
+        for i in range(v.n_triangles):
+            t = v.triangles[i]
+            for p in (t.a, t.b, t.c):
+                f.write(f"v {fmt(p[0])} {fmt(p[1])} {fmt(p[2])}\n")
+        last = None
+        for i in range(v.n_triangles):
+            m = v.triangles[i].material
+            if m != last:
+                f.write(f"usemtl {MESH_MTL[m][0]}\ns off\n")
+                last = m
+            f.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+
+
+def test_station_style_mesh_round_trips_through_obj(rt, oracle, tmp_path):
+    """Config 3 data path: the generated mesh written as .obj/.mtl and read back gives the
+    same triangles, normals and material values, hence the same BVH and the same image."""
+    a = rt.Scene.builtin("mesh:1500")
+    path = os.path.join(tmp_path, "station.obj")
+    dump_obj(a, path)
+    b = rt.Scene.from_obj(path)
+    va, vb = a.view, b.view
+    assert va.n_triangles == vb.n_triangles and vb.n_spheres == 0
+    mat = lambda v, i: bytes(v.materials[v.triangles[i].material])
+    for i in range(va.n_triangles):
+        ta, tb = va.triangles[i], vb.triangles[i]
+        assert (list(ta.a), list(ta.b), list(ta.c), list(ta.n)) == (list(tb.a), list(tb.b), list(tb.c), list(tb.n))
+        assert mat(va, i) == mat(vb, i), i
+    assert [bytes(va.lights[k]) for k in range(8)] != []  # both have 8 lights (mesh moved by +20)
+    assert np.array_equal(a.nodes()["box"], b.nodes()["box"])
+    assert np.array_equal(a.leaf_refs(), b.leaf_refs())

@@ -13,7 +13,9 @@ for f in sorted(glob.glob(root + "/*/**/*counter_collection.csv", recursive=True
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if pat in k and "true>" not in k.split("render_kernel")[-1].split(",")[-1]:
+            args = k.split(pat + "<")[-1].split(">")[0].split(",") if pat + "<" in k else []
+            counting = len(args) > 1 and args[1].strip() == "true"   # render_kernel<PRUNE, COUNT, LDS>
+            if pat in k and not counting:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(acc):
     v = acc[name]
