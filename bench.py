@@ -41,6 +41,8 @@ PEAK_HBM_GBPS = 8000.0     # HBM3E spec
 BYTES_PER_RAY = 128        # 56-B ray record written+read once + 8-B hit record x2
 SEED = 0x5EED1234
 
+_ORBIT = None
+
 WORKLOADS = {
     # name: (scene, config name, width, height, (view w,h,d), rays per pixel, lens)
     "c1": ("bench1", "bench1", 800, 600, (8, 6, 7), 1, None),
@@ -48,11 +50,21 @@ WORKLOADS = {
     "c3": ("mesh:100000", "mesh", 1920, 1080, (16, 9, 10), 4, None),
     "c4-glossy": ("bench5", "bench5", 1920, 1080, (16, 9, 10), 64, None),
     "c4-dof": ("bench4", "bench4", 1920, 1080, (16, 9, 10), 64, 0.05),
+    # config 5: animation at 4K -- every step is the NEXT frame of the orbit (objects
+    # re-evaluated, sahBVH rebuilt on the host, scene re-uploaded inside the timed region)
+    "c5": ("orbit animation", None, 3840, 2160, (16, 9, 8), 4, None),
 }
 
 
-def make_world(name: str):
+def make_world(name: str, t: float = 0.0):
     scene_name, cfg_name, w, h, view, rpp, lens = WORKLOADS[name]
+    if cfg_name is None:
+        anim = importlib.import_module("ray-tracer_amd.animation")
+        global _ORBIT
+        if _ORBIT is None:
+            _ORBIT = anim.parse_scene_description(anim.ORBIT_DESCRIPTION)
+        cfg = rt.Config(image_width=w, image_height=h, anti_aliasing=rpp, reflection_depth=6)
+        return _ORBIT.world_at(t, cfg)
     cfg = rt.default_config(cfg_name)
     cfg.image_width, cfg.image_height = w, h
     cfg.view_width, cfg.view_height, cfg.view_distance = view
@@ -155,14 +167,24 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    animated = WORKLOADS[args.workload][1] is None
+    frame_no = [0]
+
+    def submit():
+        if animated:
+            frame_no[0] += 1
+            df.submit(args.flags, make_world(args.workload, float(frame_no[0])))
+        else:
+            df.submit(args.flags)
+
     for _ in range(args.warmup):
-        df.submit(args.flags)
+        submit()
     fence()
     st = df.r.collect(df.streams[0].cuda_stream)   # per-frame ray counters of this rank (same every frame)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        df.submit(args.flags)
+        submit()
     fence()
     dt = time.perf_counter() - t0
 

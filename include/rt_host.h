@@ -80,6 +80,9 @@ int rth_generate_grids(uint64_t seed, int32_t n_grids, int32_t aa, float *out);
 /* writePPM (src/Main.hs:128-138) and its 8-bit quantisation. */
 int rth_write_ppm(const char *path, int32_t w, int32_t h, const float *rgb);
 void rth_quantize(const float *rgb, size_t n, uint8_t *out);
+/* Output stage after the GPU's rt_quantize_async: the same pixels as writePPM's P3 text, as
+ * binary P6 (3 bytes per pixel instead of up to 12 characters). */
+int rth_write_ppm_binary(const char *path, int32_t w, int32_t h, const uint8_t *rgb8);
 
 /* Material table of Materials.hs by name ("whiteDull", "glass", ...). */
 int rth_material_by_name(const char *name, rt_material *out);

@@ -121,6 +121,7 @@ HOST_SYMBOLS = [
     "rth_scene_add_light", "rth_scene_add_bench6_lights", "rth_scene_build_bvh",
     "rth_scene_view", "rth_scene_n_objects", "rth_scene_bvh_depth", "rth_default_config",
     "rth_config_to_camera", "rth_generate_grids", "rth_write_ppm", "rth_quantize",
+    "rth_write_ppm_binary",
     "rth_material_by_name", "rth_make_triangle",
 ]
 
@@ -165,6 +166,7 @@ def host_lib() -> C.CDLL:
         L.rth_write_ppm.argtypes = [C.c_char_p, i32, i32, C.POINTER(f32)]
         L.rth_quantize.argtypes = [C.POINTER(f32), C.c_size_t, C.POINTER(C.c_uint8)]
         L.rth_quantize.restype = None
+        L.rth_write_ppm_binary.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_uint8)]
         L.rth_material_by_name.argtypes = [C.c_char_p, C.POINTER(Material)]
         L.rth_make_triangle.argtypes = [f32 * 3, f32 * 3, f32 * 3, i32, C.POINTER(Triangle)]
         L.rth_make_triangle.restype = None
@@ -408,6 +410,14 @@ def write_ppm(path: str, w: int, h: int, pixels: np.ndarray) -> None:
     a = np.ascontiguousarray(pixels, np.float32)
     assert a.size == w * h * 3
     if host_lib().rth_write_ppm(path.encode(), w, h, a.ctypes.data_as(C.POINTER(f32))) != 0:
+        raise RtError(f"cannot write {path}")
+
+
+def write_ppm_binary(path: str, w: int, h: int, rgb8: np.ndarray) -> None:
+    """Binary P6 of already quantised pixels (what rt_quantize_async produces on the GPU)."""
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    assert a.size == w * h * 3
+    if host_lib().rth_write_ppm_binary(path.encode(), w, h, a.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
         raise RtError(f"cannot write {path}")
 
 

@@ -1044,6 +1044,17 @@ int rth_write_ppm(const char *path, int32_t w, int32_t h, const float *rgb) {
   return RT_OK;
 }
 
+int rth_write_ppm_binary(const char *path, int32_t w, int32_t h, const uint8_t *rgb8) {
+  if (!path || !rgb8 || w <= 0 || h <= 0) return RT_ERR_INVALID;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return RT_ERR_INVALID;
+  std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+  size_t n = (size_t)w * h * 3;
+  bool ok = std::fwrite(rgb8, 1, n, f) == n;
+  std::fclose(f);
+  return ok ? RT_OK : RT_ERR_INVALID;
+}
+
 int rth_material_by_name(const char *name, rt_material *out) {
   if (!name || !out) return RT_ERR_INVALID;
   return named_material(name, out) ? RT_OK : RT_ERR_INVALID;

@@ -87,10 +87,14 @@ class DistributedFrame:
         """The most recently submitted frame (valid after finish())."""
         return self.frames[(self.k - 1) % self.depth] if self.k else self.frames[0]
 
-    def submit(self, flags: int = 0) -> None:
-        """Enqueue one frame; returns without waiting for the GPU."""
+    def submit(self, flags: int = 0, world=None) -> None:
+        """Enqueue one frame; returns without waiting for the GPU.  `world` (animation): the
+        frame's own World, uploaded to the frame's context first (rt_upload_scene frees the
+        previous scene, which waits for that context's frame in flight)."""
         slot = self.k % self.depth
         rs, r = self.streams[slot], self.renderers[slot]
+        if world is not None:
+            r.set_world(world)
         if self.nranks == 1:
             r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
             self.k += 1

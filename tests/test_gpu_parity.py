@@ -128,3 +128,16 @@ def test_partition_tiles_assemble_to_full_frame(rt, renderer):
     renderer.collect()
     renderer.set_partition(0, 1)
     assert np.array_equal(out.cpu().numpy().reshape(-1, 3), full)
+
+
+def test_gpu_quantize_equals_write_ppm_rounding(rt, renderer):
+    """rt_quantize_async == truncate(255 * clamp x) of writePPM (Main.hs:99-101,131)."""
+    import torch
+    x = torch.tensor([-1.0, 0.0, 0.5, 0.999, 1.0, 7.5, 1 / 255, float("inf"), float("-inf"), float("nan")],
+                     dtype=torch.float32, device="cuda:0")
+    rnd = torch.rand(100003, dtype=torch.float32, device="cuda:0") * 1.5 - 0.25
+    x = torch.cat([x, rnd])
+    out = torch.zeros(x.numel(), dtype=torch.uint8, device="cuda:0")
+    renderer.quantize_async(x.data_ptr(), out.data_ptr(), x.numel())
+    renderer.collect()
+    assert np.array_equal(out.cpu().numpy(), rt.quantize(x.cpu().numpy()))

@@ -163,6 +163,17 @@ def test_write_ppm_format(rt, tmp_path):
     assert lines[2].split() == ["255", "0", "0", "0", "127", "0", "0", "0", "255", "255", "0", "63"]
 
 
+def test_binary_ppm_holds_the_same_pixels_as_p3(rt, tmp_path):
+    px = np.random.default_rng(1).random((6 * 4, 3), np.float32) * 1.4 - 0.2
+    p3, p6 = os.path.join(tmp_path, "a.ppm"), os.path.join(tmp_path, "b.ppm")
+    rt.write_ppm(p3, 6, 4, px)
+    rt.write_ppm_binary(p6, 6, 4, rt.quantize(px))
+    text = open(p3).read().split("\n")
+    raw = open(p6, "rb").read()
+    assert raw.startswith(b"P6\n6 4\n255\n")
+    assert list(raw[len(b"P6\n6 4\n255\n"):]) == [int(x) for x in text[2].split()]
+
+
 def test_tile_partition_covers_frame_once(rt):
     """Static interleaved tile split (index math mirrored from rt_api.hip compute_tiling)."""
     for (w, h, spp) in [(1920, 1080, 16), (200, 150, 4), (33, 17, 64), (5, 3, 1)]:
