@@ -131,6 +131,8 @@ def main() -> None:
     ap.add_argument("--flags", type=int, default=0, help="rt_render flags (1 = FMA build)")
     ap.add_argument("--frames-in-flight", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="self-test: run the gather/assemble path with one rank and check the frame")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,8 +146,9 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the trace/shade path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    if world_size > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     world = make_world(args.workload)
@@ -159,7 +162,8 @@ def main() -> None:
 
     # F contexts render alternate frames on their own streams (ray-tracer_amd/distributed.py):
     # the next frame's blocks fill the wave slots the current frame's tail leaves empty
-    df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight)
+    df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight,
+                              force_collective=args.force_collective)
 
     def fence():
         df.finish()
@@ -217,7 +221,16 @@ def main() -> None:
                        "parallelism": f"tiles%{world_size}" + ("+rccl_gather" if world_size > 1 else ""),
                        "sample_seed": SEED},
         }
-    if world_size == 1:
+    if args.force_collective:
+        ref = torch.zeros_like(df.frames[0])
+        df.r.set_partition(0, 1)
+        df.r.render_async(ref.data_ptr(), 0, args.flags, df.streams[0].cuda_stream)
+        df.r.collect(df.streams[0].cuda_stream)
+        same = all(torch.equal(ref, f) for f in df.frames)
+        out["config"]["collective_path_frame_identical"] = bool(same)
+        if not same:
+            raise SystemExit("gathered + assembled frame differs from the directly rendered one")
+    if world_size == 1 and not args.force_collective:
         # Roofline of the dominant kernel.  Its launch duration is measured with HIP events
         # recorded by the library on the launch stream right around render_kernel
         # (rt_stats.ms_kernel), one frame in flight, averaged over `steps` launches -- the
@@ -263,7 +276,7 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(out), flush=True)
     df.close()
-    if world_size > 1:
+    if world_size > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

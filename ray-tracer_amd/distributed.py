@@ -53,7 +53,8 @@ class DistributedFrame:
     After `finish()`, rank 0 holds the newest frames in `self.frames` ([H*W*3] float32 each,
     render's pixel order)."""
 
-    def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 2):
+    def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 2,
+                 force_collective: bool = False):
         self.rank, self.nranks, self.device = rank, nranks, device
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
@@ -72,7 +73,10 @@ class DistributedFrame:
         # queue: no overlap at all.)
         self.streams = [torch.cuda.ExternalStream(r.stream, device=device) for r in self.renderers]
         self.k = 0
-        if nranks == 1:
+        # force_collective: run the gather/assemble path even with one rank (self-test on a
+        # one-GPU box of exactly the code the 8-GPU job runs)
+        self.collective = nranks > 1 or force_collective
+        if not self.collective:
             return
         self.mine = [torch.zeros(self.stride, dtype=torch.float32, device=device)
                      for _ in range(self.depth)]
@@ -95,7 +99,7 @@ class DistributedFrame:
         rs, r = self.streams[slot], self.renderers[slot]
         if world is not None:
             r.set_world(world)
-        if self.nranks == 1:
+        if not self.collective:
             r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
             self.k += 1
             return
@@ -119,7 +123,7 @@ class DistributedFrame:
 
     def finish(self) -> None:
         """Wait until every submitted frame is rendered, gathered and assembled."""
-        if self.nranks > 1:
+        if self.collective:
             for w in self.works:
                 if w is not None:
                     w.wait()

@@ -141,3 +141,23 @@ def test_gpu_quantize_equals_write_ppm_rounding(rt, renderer):
     renderer.quantize_async(x.data_ptr(), out.data_ptr(), x.numel())
     renderer.collect()
     assert np.array_equal(out.cpu().numpy(), rt.quantize(x.cpu().numpy()))
+
+
+def test_collective_path_self_test_on_one_gpu():
+    """The gather + assemble + frames-in-flight code of ray-tracer_amd/distributed.py, run with
+    ONE rank over RCCL (bench.py --force-collective): the assembled frames must equal the
+    directly rendered frame.  (More ranks need more GPUs; the layout for N > 1 is covered on
+    CPU over gloo and by test_partition_tiles_assemble_to_full_frame.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "6",
+                        "--warmup", "2", "--no-cpu-baseline", "--force-collective"],
+                       env=env, capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["config"]["collective_path_frame_identical"] is True
