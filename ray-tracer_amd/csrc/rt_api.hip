@@ -536,6 +536,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
       float a = std::fabs(b[k]);
       if (!(b[k] == 0.0f || (a >= 1.4551915228366852e-11f && a <= 5.764607523034235e17f))) c->boxes_safe = 0;
     }
+    if (!(b[0] <= b[1] && b[2] <= b[3] && b[4] <= b[5])) c->boxes_safe = 0;  // min <= max (entry/exit form)
   }
   c->have_scene = true;
   return RT_OK;

@@ -111,9 +111,13 @@ DEVI float mdiv(float a, float d, float r) {
 // hitsBox (BoundingVolumeHierarchy.hs:191-204): six IEEE divisions, slab ends
 // swapped by the sign test `d >= 0`, six interval comparisons.  t0/t1 out for the
 // (result-preserving) range pruning.  SAFE selects the exact-reciprocal quotients.
+// entry = max of the three slab entries, exit = min of the three slab exits.  On the SAFE
+// path no quotient is NaN (finite operands, |d| >= 2^-40) and every box has min <= max
+// (checked at upload), so t_i0 <= t_i1 on each axis by monotonicity of rounding and the six
+// cross-axis comparisons of the reference collapse to ONE: some t_i0 > t_j1  <=>  entry > exit.
 template <bool SAFE>
 DEVI bool hits_box(V3 b, V3 d, const RayDiv &rd, float l, float r, float bo, float t, float n, float f,
-                   float &e0, float &e1, float &e2, float &x0, float &x1, float &x2) {
+                   float &entry, float &exit_) {
   float ax0 = (d.x >= 0 ? l : r) - b.x, ax1 = (d.x >= 0 ? r : l) - b.x;
   float ay0 = (d.y >= 0 ? bo : t) - b.y, ay1 = (d.y >= 0 ? t : bo) - b.y;
   float az0 = (d.z >= 0 ? n : f) - b.z, az1 = (d.z >= 0 ? f : n) - b.z;
@@ -127,8 +131,9 @@ DEVI bool hits_box(V3 b, V3 d, const RayDiv &rd, float l, float r, float bo, flo
     ty0 = ay0 / d.y; ty1 = ay1 / d.y;
     tz0 = az0 / d.z; tz1 = az1 / d.z;
   }
-  e0 = tx0; e1 = ty0; e2 = tz0;
-  x0 = tx1; x1 = ty1; x2 = tz1;
+  entry = fmaxf(fmaxf(tx0, ty0), tz0);
+  exit_ = fminf(fminf(tx1, ty1), tz1);
+  if (SAFE) return !(entry > exit_);
   return !(tx0 > ty1 || tx0 > tz1 || tx1 < ty0 || tx1 < tz0 || ty0 > tz1 || ty1 < tz0);
 }
 
@@ -216,29 +221,26 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       const float4 *np = node_rec<LDS>(P, sc, cur);
       float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
       int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
-      float le0, le1, le2, lx0, lx1, lx2, re0, re1, re2, rx0, rx1, rx2;
+      float le, lx, re = 0.0f, rx = 0.0f;
       bool hl, hr = false;
       if (all_safe) {
-        hl = hits_box<true>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le0, le1, le2, lx0, lx1, lx2);
-        if (rref != REF_NONE)
-          hr = hits_box<true>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re0, re1, re2, rx0, rx1, rx2);
+        hl = hits_box<true>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
+        if (rref != REF_NONE) hr = hits_box<true>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
       } else {
-        hl = hits_box<false>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le0, le1, le2, lx0, lx1, lx2);
-        if (rref != REF_NONE)
-          hr = hits_box<false>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re0, re1, re2, rx0, rx1, rx2);
+        hl = hits_box<false>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
+        if (rref != REF_NONE) hr = hits_box<false>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
       }
       if (COUNT) cn.box += (rref != REF_NONE) ? 2 : 1;
       bool left_first = true;
       if (PRUNE) {
-        float lim = prune_limit(best_t);
-        if (hl && (le0 > lim || le1 > lim || le2 > lim || lx0 < BEHIND || lx1 < BEHIND || lx2 < BEHIND))
-          hl = false;
-        if (hr && (re0 > lim || re1 > lim || re2 > lim || rx0 < BEHIND || rx1 < BEHIND || rx2 < BEHIND))
-          hr = false;
-        if (hl && hr) {
-          float el = fmaxf(fmaxf(le0, le1), le2), er = fmaxf(fmaxf(re0, re1), re2);
-          left_first = !(er < el);
-        }
+        // a slab entry beyond the limit on any axis <=> entry > lim; an exit behind the origin
+        // on any axis <=> exit < BEHIND.  (A NaN quotient -- plain-division path only: zero
+        // direction component with the origin on a box plane -- is ignored by max/min; the
+        // prune then rests on a real axis and is just as valid.)
+        const float lim = prune_limit(best_t);
+        if (hl && (le > lim || lx < BEHIND)) hl = false;
+        if (hr && (re > lim || rx < BEHIND)) hr = false;
+        left_first = !(re < le);
       }
       if (hl && hr) {
         int first = left_first ? lref : rref, second = left_first ? rref : lref;
