@@ -313,6 +313,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.view_h = cam.view_h;
   p.view_d = cam.view_d;
   p.lens = cam.lens;
+  p.half_view_w = cam.view_w / 2.0f;
+  p.half_view_h = cam.view_h / 2.0f;
+  p.half_lens = cam.lens / 2;
   for (int i = 0; i < 3; ++i) {
     p.eye[i] = cam.eye[i];
     p.u[i] = cam.u[i];
@@ -546,6 +549,8 @@ int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
   if (!c || !cam) return RT_ERR_INVALID;
   if (cam->img_w < 1 || cam->img_h < 1 || cam->img_w > 65536 || cam->img_h > 65536)
     return fail(c, RT_ERR_INVALID, "image size %dx%d out of range", cam->img_w, cam->img_h);
+  if ((uint64_t)cam->img_w * (uint64_t)cam->img_h >= (1ull << 32))
+    return fail(c, RT_ERR_LIMIT, "image of %dx%d pixels exceeds 2^32", cam->img_w, cam->img_h);
   if (cam->aa < 1 || cam->aa > 32) return fail(c, RT_ERR_INVALID, "aa=%d out of range [1,32]", cam->aa);
   if (cam->max_depth < 0 || cam->max_depth > MAX_DEPTH)
     return fail(c, RT_ERR_LIMIT, "max_depth=%d out of range [0,%d]", cam->max_depth, MAX_DEPTH);

@@ -53,6 +53,7 @@ struct RenderParams {
   int W, H, max_depth, pad0;
   float view_w, view_h, view_d, lens;
   float eye[3], u[3], v[3], w[3], ambient[3];
+  float half_view_w, half_view_h, half_lens;  // view_w / 2, view_h / 2, lens / 2 (IEEE, host)
   // tiling / partition
   int tile_w, tile_h, tiles_x, tile_samples;
   int rank, nranks, n_local_tiles, compact;

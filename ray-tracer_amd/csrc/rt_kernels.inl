@@ -323,14 +323,14 @@ DEVI void orthonormal(V3 w, V3 &u, V3 &v) {
 DEVI void get_ray(const RenderParams &P, float i, float j, float r1, float r2, V3 &base, V3 &dirn) {
   float lens = P.lens;
   V3 eye = ld3(P.eye), u = ld3(P.u), v = ld3(P.v), ww = ld3(P.w);
-  float r1l = r1 * lens, r2l = r2 * lens, l2 = lens / 2;
+  float r1l = r1 * lens, r2l = r2 * lens, l2 = P.half_lens;  // lens / 2, divided on the host
   V3 ru = subt(mk(u.x * r1l, u.y * r1l, u.z * r1l), mk(u.x * l2, u.y * l2, u.z * l2));
   V3 rv = subt(mk(v.x * r2l, v.y * r2l, v.z * r2l), mk(v.x * l2, v.y * l2, v.z * l2));
   base = add(eye, add(ru, rv));
   float vWd = P.view_w, vHt = P.view_h, vDt = P.view_d;
   float iWd = (float)P.W, iHt = (float)P.H;
-  float u_world = i * vWd / iWd - vWd / 2.0f;
-  float v_world = j * vHt / iHt - vHt / 2.0f;
+  float u_world = i * vWd / iWd - P.half_view_w;  // vWd / 2.0 and vHt / 2.0: same IEEE quotients,
+  float v_world = j * vHt / iHt - P.half_view_h;  // formed once on the host
   float w_world = -vDt;
   V3 u_dir = multiply(u, u_world);
   V3 v_dir = multiply(v, v_world);
@@ -564,8 +564,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       PH_MARK(7);
       if (active) {
         // render (RayTracer.hs:18-23): list position k uses grid k mod n_grids
-        size_t kpix = (size_t)py * P.W + px;
-        const float *F = P.f6 + ((kpix % (size_t)P.n_grids) * (size_t)P.spp + smp) * 6;
+        const unsigned kpix = (unsigned)py * (unsigned)P.W + (unsigned)px;  // < 2^32 (checked on the host)
+        const float *F = P.f6 + ((size_t)(kpix % (unsigned)P.n_grids) * (size_t)P.spp + smp) * 6;
         float fi = (float)px, fj = (float)(P.H - 1 - py);
         get_ray(P, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
         s0 = F[4];
@@ -693,11 +693,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       const bool head = (lane == 0) || key_prev != key;
       const bool tail = contrib && ((lane == 63) || key_next != key);
       const unsigned long long heads = __ballot(head);
+      // level 1: a pixel's lanes are its spp consecutive samples, runs cannot be longer
+      const int scan_span = (level == 1 && P.spp < 64) ? P.spp : 64;
       if (~heads) {  // some run is longer than one lane
         const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
         const int start = 63 - __clzll(upto);  // first lane of this lane's run
 #pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        for (int dlt = 1; dlt < scan_span; dlt <<= 1) {
           long long ur = __shfl_up(cr, dlt), ug = __shfl_up(cg, dlt), ub = __shfl_up(cb, dlt);
           if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
         }
