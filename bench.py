@@ -130,6 +130,7 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--flags", type=int, default=0, help="rt_render flags (1 = FMA build)")
     ap.add_argument("--frames-in-flight", type=int, default=2)
+    ap.add_argument("--share-gpu", default="auto", choices=["auto", "yes", "no"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="self-test: run the gather/assemble path with one rank and check the frame")
@@ -163,7 +164,7 @@ def main() -> None:
     # F contexts render alternate frames on their own streams (ray-tracer_amd/distributed.py):
     # the next frame's blocks fill the wave slots the current frame's tail leaves empty
     df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight,
-                              force_collective=args.force_collective)
+                              force_collective=args.force_collective, share_gpu=args.share_gpu)
 
     def fence():
         df.finish()
@@ -217,7 +218,7 @@ def main() -> None:
                        "rays_per_frame": int(rays_frame),
                        "rays_primary": int(rays[1].item()), "rays_shadow": int(rays[2].item()),
                        "rays_bounce": int(rays[3].item()),
-                       "frames_in_flight": args.frames_in_flight,
+                       "frames_in_flight": df.mode[0], "contexts_share_wave_slots": df.mode[1],
                        "parallelism": f"tiles%{world_size}" + ("+rccl_gather" if world_size > 1 else ""),
                        "sample_seed": SEED},
         }
@@ -238,6 +239,7 @@ def main() -> None:
         # reports as that kernel's average.  (With 2 frames in flight kernels overlap, so
         # the per-kernel duration is no longer the per-frame cost; `value` is the throughput.)
         r, stream = df.r, df.streams[0].cuda_stream
+        r.set_concurrency(1)   # the whole GPU for the one frame in flight
         kms, lms = [], []
         for _ in range(args.steps):
             r.render_async(df.frames[0].data_ptr(), 0, args.flags, stream)

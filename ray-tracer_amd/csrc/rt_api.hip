@@ -60,6 +60,7 @@ struct rt_ctx {
   size_t d_ids_count = 0;
   bool prepared = false;
   int stack_depth = 8;
+  int grid_div = 1;                // RT_GRID_DIV: launch 1/grid_div of the resident capacity
   int batches = 0;                 // RT_BATCHES
   int refr_cap = 0, refl_cap = 0;  // RT_REFR_CAP / RT_REFL_CAP (0 = default)
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
@@ -369,7 +370,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  cfg.grid = std::max(1, std::min(c->n_cus * per_cu, want));
+  cfg.grid = std::max(1, std::min(c->n_cus * per_cu / std::max(1, c->grid_div), want));
   if (cfg.grid * WAVES_PER_BLOCK > c->scratch_waves)
     return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
 
@@ -459,6 +460,7 @@ int rt_init(int device, rt_ctx **out) {
   c->n_cus = prop.multiProcessorCount;
   if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_LDS_SCENE")) c->lds_scene_mode = std::atoi(e);
+  if (const char *e = std::getenv("RT_GRID_DIV")) c->grid_div = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("RT_BATCHES")) c->batches = std::atoi(e);
   if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
@@ -631,6 +633,13 @@ int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, 
   int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, s, d_rgb, d_rgb8, n);
   HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_set_concurrency(rt_ctx *c, int32_t n) {
+  if (!c) return RT_ERR_INVALID;
+  if (n < 1 || n > 16) return fail(c, RT_ERR_INVALID, "n_concurrent=%d out of range [1,16]", n);
+  c->grid_div = n;
   return RT_OK;
 }
 

@@ -54,12 +54,18 @@ class DistributedFrame:
     render's pixel order)."""
 
     def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 2,
-                 force_collective: bool = False):
+                 force_collective: bool = False, share_gpu: str = "auto"):
+        """share_gpu: "auto" times a few frames at start-up and keeps the fastest of
+        {1 frame in flight; `in_flight` frames, whole-GPU grids; `in_flight` frames, each
+        context launching 1/in_flight of the wave slots (rt_set_concurrency)} -- which one wins
+        depends on the frame's size and on how the runtime maps the contexts' streams onto
+        hardware queues; "yes" / "no" force the choice."""
         self.rank, self.nranks, self.device = rank, nranks, device
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
         for r in self.renderers:
             r.set_partition(rank, nranks)
+        self.mode = self._choose_mode(share_gpu)
         self.r = self.renderers[0]
         til = self.r.tiling()
         self.tile_floats, self.stride = partition_layout(til.n_tiles, til.tile_w, til.tile_h, nranks)
@@ -85,6 +91,41 @@ class DistributedFrame:
         self.works = [None] * self.depth
         self.asm_stream = torch.cuda.Stream(device=device)
         self.asm_done = [None] * self.depth
+
+    def _choose_mode(self, share_gpu: str):
+        """(frames in flight, contexts share the wave slots) -- local timing only, no collective."""
+        if self.depth == 1:
+            return (1, False)
+        if share_gpu in ("yes", "no"):
+            share = share_gpu == "yes"
+            for r in self.renderers:
+                r.set_concurrency(self.depth if share else 1)
+            return (self.depth, share)
+        import time
+        w = self.renderers[0].world
+        scratch = [torch.zeros(w.height * w.width * 3 + 4096, dtype=torch.float32, device=self.device)
+                   for _ in range(self.depth)]
+        best = None
+        for depth, share in ((1, False), (self.depth, False), (self.depth, True)):
+            for r in self.renderers:
+                r.set_concurrency(depth if share else 1)
+            times = []
+            for rep in range(3):
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for k in range(2 * self.depth):
+                    j = k % depth
+                    self.renderers[j].render_tiles_async(scratch[j].data_ptr(), 0, 0)
+                torch.cuda.synchronize(self.device)
+                times.append(time.perf_counter() - t0)
+            t = min(times[1:])
+            if best is None or t < best[0] * 0.98:   # prefer the simpler mode unless 2 % faster
+                best = (t, depth, share)
+        _, depth, share = best
+        for r in self.renderers:
+            r.set_concurrency(depth if share else 1)
+        self.depth = depth
+        return (depth, share)
 
     @property
     def frame(self):

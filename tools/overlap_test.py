@@ -10,7 +10,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 nr = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 world = make_world(wl)
 grids = rt.generate_grids(SEED, world.width + 10, world.camera.aa)
-for F in (1, 2, 3):
+for F in (2, 4):
     rs, bufs, streams = [], [], []
     for i in range(F):
         r = rt.Renderer(0); r.set_world(world); r.set_samples(grids); r.set_partition(0, nr)
