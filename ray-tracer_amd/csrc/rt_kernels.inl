@@ -216,8 +216,11 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
   // denormal direction component, or an out-of-range scene)
   const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
+  // "while-while" form: all lanes first descend until each stands on a leaf (or is done),
+  // then the leaves are processed together -- node code and primitive code are not
+  // interleaved per iteration, which keeps more lanes busy in both.
   while (cur != STOP) {
-    if (cur >= 0) {
+    while (cur >= 0) {
       const float4 *np = node_rec<LDS>(P, sc, cur);
       float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
       int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
@@ -257,7 +260,8 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       } else {
         cur = STOP;
       }
-    } else {
+    }
+    if (cur != STOP) {
       // leaf: records first .. first+count-1 (reversed list order)
       int first = -1 - cur;
       const float4 *pp = prim_rec<LDS>(P, sc, first);
