@@ -1,8 +1,12 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
 seeded inputs.  The oracle is a restatement of the reference (PARITY UNPINNED: the
 reference has no tests or golden vectors, see oracle/rt_oracle.c)."""
+import ctypes as C
+
 import numpy as np
 import pytest
+
+f32 = C.c_float
 
 from conftest import make_world
 
@@ -161,3 +165,66 @@ def test_collective_path_self_test_on_one_gpu():
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert j["config"]["collective_path_frame_identical"] is True
+
+
+@pytest.mark.parametrize("rpp,depth", [(1, 6), (9, 6), (100, 3), (4, 1), (4, 2), (4, 0)])
+def test_sample_counts_and_depths(rt, oracle, renderer, rpp, depth):
+    """Edge shapes of the work decomposition: 1 sample per pixel, a non-power-of-two count
+    (aa 3), more than one wave per pixel (aa 10 -> 100 samples, chunked packets), and the
+    recursion limits wMaxDepth = 0 (black frame, raytrace _ 0 = black), 1 (no bounce), 2."""
+    w = make_world(rt, "bench1", 72, 40, rpp, depth=depth)
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(
+        rt, oracle, renderer, w, 21, 0, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0
+    assert g_st.rays_total == o_st.rays_total
+    check_image(rt, g_rgb, o_rgb)
+    if depth == 0:
+        assert not g_rgb.any() and g_st.rays_total == 0
+
+
+def test_empty_scene_and_no_lights(rt, oracle, renderer):
+    """`Empty` BVH (Types.hs:99): every ray misses -> black.  No lights: ambient term only
+    (getDirectColor [] = ambient * diffuse, RayTracer.hs:91)."""
+    mats = [rt.material("whiteDull")]
+    empty = rt.Scene.create([], [], [], mats, [])
+    cfg = rt.default_config("bench1")
+    cfg.image_width, cfg.image_height, cfg.anti_aliasing = 40, 24, 4
+    w = rt.config_to_world(cfg, empty)
+    grids = rt.generate_grids(3, 50, w.camera.aa)
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    rgb, ids, st = renderer.render(0, want_hit_ids=True)
+    assert not rgb.any() and (ids == rt.HIT_NONE).all() and st.rays_total == st.rays_primary == 40 * 24 * 4
+    tris = [rt.make_triangle((-50, 0, -50), (-50, 0, 50), (50, 0, 50), 0)]
+    unlit = rt.Scene.create([], tris, [rt.REF_TRIANGLE | 0], mats, [])
+    w = rt.config_to_world(cfg, unlit)
+    (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 4, 0, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_shadow == 0 == o_st.rays_shadow
+    assert np.allclose(g_rgb, o_rgb, rtol=1e-6, atol=1e-7)
+    assert g_rgb.max() == pytest.approx(0.1, rel=1e-5)
+
+
+def test_axis_aligned_rays_take_the_plain_division_path(rt, oracle, renderer):
+    """Rays with an exactly zero direction component (camera looking straight down an axis at
+    an axis-aligned scene; reflections off axis-aligned faces) leave the exact-reciprocal path
+    (0/0 and x/0 must behave like the reference's divisions, hitsBox :191-204)."""
+    mats = [rt.material("whiteMirror"), rt.material("redDull")]
+    tris = [rt.make_triangle((-4, -4, 0), (4, -4, 0), (4, 4, 0), 0),
+            rt.make_triangle((-4, -4, 0), (4, 4, 0), (-4, 4, 0), 0),
+            rt.make_triangle((-9, -9, 12), (9, 9, 12), (9, -9, 12), 1),
+            rt.make_triangle((-9, -9, 12), (-9, 9, 12), (9, 9, 12), 1)]
+    lights = [rt.Light((f32 * 3)(0, 0, 6), (f32 * 3)(0, 0, 0), (f32 * 3)(0, 0, 0), (f32 * 3)(0.5, 0.5, 0.5))]
+    sc = rt.Scene.create([], tris, [rt.REF_TRIANGLE | i for i in range(4)], mats, lights)
+    cfg = rt.Config(image_width=32, image_height=32, view_width=4, view_height=4, view_distance=4,
+                    reflection_depth=4, anti_aliasing=1, eye=(0.0, 0.0, 8.0), look_at=(0.0, 0.0, 0.0))
+    w = rt.config_to_world(cfg, sc)
+    grids = np.zeros((42, 1, 6), np.float32)      # no jitter: the centre column / row have d.x == 0 / d.y == 0
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    g_rgb, g_ids, g_st = renderer.render(0, want_hit_ids=True)
+    o_rgb, o_ids, o_st = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
+    assert (g_ids != rt.HIT_NONE).any()
+    check_image(rt, g_rgb, o_rgb)
