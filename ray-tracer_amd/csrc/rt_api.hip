@@ -411,7 +411,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.order = c->d_order;
   HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
-  HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 16 * sizeof(unsigned long long), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
   // pixel accumulators start at zero (the kernel only adds, with atomics)
   HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h * 3 * sizeof(long long), s));
   HIP_TRY(c, hipEventRecord(c->ev0, s));
@@ -482,7 +482,7 @@ int rt_init(int device, rt_ctx **out) {
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 16) * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 32) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
     return RT_ERR_DEVICE;
@@ -670,7 +670,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   if (!c || !out || max_waves < 1) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
-  int n = std::min<int>(max_waves, 16384 + 4);  // the last 4 rows: phase sums of a profiling build
+  int n = std::min<int>(max_waves, 16384 + 8);  // the last 8 rows: phase sums of a profiling build
   HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }

@@ -38,7 +38,7 @@ constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS s
 
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
 constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
-constexpr int TAG_SLOTS = 256;  // LDS tag table per wave (conflict-free accumulation)
+constexpr int POINT_WORDS = 6 * 64;  // LDS per wave: x, y, z, s0, s1, occlusion mask of the step's <= 64 shaded points
 constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)
@@ -102,7 +102,7 @@ int occupancy_strict(bool prune, bool count, bool lds_scene, bool flat, size_t l
 int occupancy_fma(bool prune, bool count, bool lds_scene, bool flat, size_t lds_bytes);
 
 inline size_t lds_bytes_for(int stack_depth) {
-  return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + TAG_SLOTS + 32) * 4;
+  return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + POINT_WORDS + 32) * 4;
 }
 inline unsigned long long scratch_floats_per_wave(int max_depth) {
   int levels = max_depth > 1 ? max_depth - 1 : 0;  // level 1 (primary) is never queued

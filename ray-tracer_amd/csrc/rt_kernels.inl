@@ -56,7 +56,18 @@ constexpr int STOP = INT32_MIN + 1;     // traversal finished (distinct from REF
 
 struct Counters {
   unsigned box, sph, tri;
+#ifdef RT_PROFILE_PHASES
+  // per lane: loop iterations it took part in, and its 2^20 / (lanes taking part) share of each
+  // (summed over the lanes: lane-iterations and 2^20 x wave-iterations).  [0] node steps,
+  // [1] leaf steps of closest-hit traversals, [2], [3] the same for shadow traversals
+  unsigned long long iters[4], lanes[4];
+#endif
 };
+#ifdef RT_PROFILE_PHASES
+#define DIV_COUNT(cn, i) do { (cn).iters[i] += 1; (cn).lanes[i] += (1u << 20) / (unsigned)__popcll(__ballot(true)); } while (0)
+#else
+#define DIV_COUNT(cn, i)
+#endif
 
 // ---- exact division by a per-ray constant ---------------------------------------------
 // hitsBox divides six box-minus-origin differences by the three direction components.
@@ -205,6 +216,97 @@ DEVI const float4 *prim_rec(const RenderParams &P, const float4 *sc, int idx) {
   return LDS ? sc + (size_t)(P.n_node_recs + idx) * LDS_REC_F4 : P.prims + (size_t)idx * PRIM_F4;
 }
 
+// One inner node: both children's hitsBox tests, the (result-preserving) pruning and ordering,
+// then the move -- descend, or pop, or stop.
+template <bool PRUNE, bool COUNT, bool LDS>
+DEVI void node_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
+                    bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
+  const float4 *np = node_rec<LDS>(P, sc, cur);
+  float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+  int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
+  float le, lx, re = 0.0f, rx = 0.0f;
+  bool hl, hr = false;
+  if (all_safe) {
+    hl = hits_box<true>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
+    if (rref != REF_NONE) hr = hits_box<true>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
+  } else {
+    hl = hits_box<false>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
+    if (rref != REF_NONE) hr = hits_box<false>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
+  }
+  if (COUNT) cn.box += (rref != REF_NONE) ? 2 : 1;
+  bool left_first = true;
+  if (PRUNE) {
+    // a slab entry beyond the limit on any axis <=> entry > lim; an exit behind the origin
+    // on any axis <=> exit < BEHIND.  (A NaN quotient -- plain-division path only: zero
+    // direction component with the origin on a box plane -- is ignored by max/min; the
+    // prune then rests on a real axis and is just as valid.)
+    const float lim = prune_limit(best_t);
+    if (hl && (le > lim || lx < BEHIND)) hl = false;
+    if (hr && (re > lim || rx < BEHIND)) hr = false;
+    left_first = !(re < le);
+  }
+  if (hl && hr) {
+    int first = left_first ? lref : rref, second = left_first ? rref : lref;
+    stack[sp * 64 + lane] = (unsigned)second;
+    ++sp;
+    cur = first;
+  } else if (hl) {
+    cur = lref;
+  } else if (hr) {
+    cur = rref;
+  } else if (sp > 0) {
+    --sp;
+    cur = (int)stack[sp * 64 + lane];
+  } else {
+    cur = STOP;
+  }
+}
+
+// One leaf: records first .. first+count-1 (reversed list order), then pop or stop.
+template <bool ANY, bool COUNT, bool LDS>
+DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, float tlimit,
+                    float &best_t, int &best_p, int &cur, int &sp, Counters &cn) {
+  int first = -1 - cur;
+  const float4 *pp = prim_rec<LDS>(P, sc, first);
+  int count = __float_as_int(pp[3].w);
+  bool done = false;
+  for (int k = 0; k < count; ++k) {
+    const float4 *q = pp + (size_t)k * (LDS ? LDS_REC_F4 : PRIM_F4);
+    float4 q0 = q[0], q1 = q[1], q3 = q[3];
+    float t;
+    bool ok;
+    if (__float_as_int(q3.x) != 0) {
+      float4 q2 = q[2];
+      ok = hit_triangle(o, d, q0, q1, q2, t);
+      if (COUNT) cn.tri += 1;
+    } else {
+      ok = hit_sphere(o, d, q0, q1.x, t);
+      if (COUNT) cn.sph += 1;
+    }
+    if (ok) {
+      if (ANY) {
+        if (t < tlimit) {
+          best_t = t;
+          best_p = first + k;
+          done = true;
+          break;
+        }
+      } else if (t < best_t || (t == best_t && first + k > best_p)) {
+        best_t = t;
+        best_p = first + k;
+      }
+    }
+  }
+  if (done) {
+    cur = STOP;
+  } else if (sp > 0) {
+    --sp;
+    cur = (int)stack[sp * 64 + lane];
+  } else {
+    cur = STOP;
+  }
+}
+
 template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
 DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, bool active, V3 o, V3 d,
                    float tlimit, float &best_t, int &best_p, Counters &cn) {
@@ -221,89 +323,105 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   // interleaved per iteration, which keeps more lanes busy in both.
   while (cur != STOP) {
     while (cur >= 0) {
-      const float4 *np = node_rec<LDS>(P, sc, cur);
-      float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-      int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
-      float le, lx, re = 0.0f, rx = 0.0f;
-      bool hl, hr = false;
-      if (all_safe) {
-        hl = hits_box<true>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
-        if (rref != REF_NONE) hr = hits_box<true>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
-      } else {
-        hl = hits_box<false>(o, d, rd, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, le, lx);
-        if (rref != REF_NONE) hr = hits_box<false>(o, d, rd, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, re, rx);
-      }
-      if (COUNT) cn.box += (rref != REF_NONE) ? 2 : 1;
-      bool left_first = true;
-      if (PRUNE) {
-        // a slab entry beyond the limit on any axis <=> entry > lim; an exit behind the origin
-        // on any axis <=> exit < BEHIND.  (A NaN quotient -- plain-division path only: zero
-        // direction component with the origin on a box plane -- is ignored by max/min; the
-        // prune then rests on a real axis and is just as valid.)
-        const float lim = prune_limit(best_t);
-        if (hl && (le > lim || lx < BEHIND)) hl = false;
-        if (hr && (re > lim || rx < BEHIND)) hr = false;
-        left_first = !(re < le);
-      }
-      if (hl && hr) {
-        int first = left_first ? lref : rref, second = left_first ? rref : lref;
-        stack[sp * 64 + lane] = (unsigned)second;
-        ++sp;
-        cur = first;
-      } else if (hl) {
-        cur = lref;
-      } else if (hr) {
-        cur = rref;
-      } else if (sp > 0) {
-        --sp;
-        cur = (int)stack[sp * 64 + lane];
-      } else {
-        cur = STOP;
-      }
+      DIV_COUNT(cn, ANY ? 2 : 0);
+      node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
     }
     if (cur != STOP) {
-      // leaf: records first .. first+count-1 (reversed list order)
-      int first = -1 - cur;
-      const float4 *pp = prim_rec<LDS>(P, sc, first);
-      int count = __float_as_int(pp[3].w);
-      bool done = false;
-      for (int k = 0; k < count; ++k) {
-        const float4 *q = pp + (size_t)k * (LDS ? LDS_REC_F4 : PRIM_F4);
-        float4 q0 = q[0], q1 = q[1], q3 = q[3];
-        float t;
-        bool ok;
-        if (__float_as_int(q3.x) != 0) {
-          float4 q2 = q[2];
-          ok = hit_triangle(o, d, q0, q1, q2, t);
-          if (COUNT) cn.tri += 1;
-        } else {
-          ok = hit_sphere(o, d, q0, q1.x, t);
-          if (COUNT) cn.sph += 1;
-        }
-        if (ok) {
-          if (ANY) {
-            if (t < tlimit) {
-              best_t = t;
-              best_p = first + k;
-              done = true;
-              break;
-            }
-          } else if (t < best_t || (t == best_t && first + k > best_p)) {
-            best_t = t;
-            best_p = first + k;
-          }
-        }
-      }
-      if (done) {
-        cur = STOP;
-      } else if (sp > 0) {
-        --sp;
-        cur = (int)stack[sp * 64 + lane];
-      } else {
-        cur = STOP;
-      }
+      DIV_COUNT(cn, ANY ? 3 : 1);
+      leaf_step<ANY, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, best_t, best_p, cur, sp, cn);
     }
   }
+}
+
+// The sampled point on light li and the shadow ray towards it (getDirectColor :96-100).
+DEVI void light_ray(const RenderParams &P, int li, V3 pt, float s0, float s1, V3 &l_dir, float &max_d) {
+  const float *Lp = P.lights + (size_t)li * 12;
+  V3 l_a = ld3(Lp + 3), l_b = ld3(Lp + 6);
+  V3 l_pt = add(ld3(Lp + 0), add(mk(l_a.x * s0, l_a.y * s0, l_a.z * s0),
+                                 mk(l_b.x * s1, l_b.y * s1, l_b.z * s1)));  // :96
+  V3 l = subt(l_pt, pt);
+  l_dir = normalize(l);
+  max_d = magnitude(l);
+}
+
+// inShadow (:231-235) for lights lo .. hi-1 (hi - lo <= 32) of the wave's shaded points, one
+// point per `hit` lane: bit (li - lo) of the result is set when light li is occluded.
+// The (point, light) pairs form ONE pool of shadow rays for the wave, light-major so that rays
+// in flight together mostly aim at the same light.  The points are parked in LDS and every
+// lane -- also those whose own ray missed -- takes the next ray of the pool whenever its
+// current one is decided ("dynamic fetch"), instead of the wave walking the light list in
+// lockstep with only the `hit` lanes and waiting for the slowest ray of every light.  An
+// occluded ray ORs its bit into the owner's mask in LDS.  The answers are per-ray facts: who
+// computes them, and in which order, cannot change them (the light ray is recomputed from
+// the same operands by the same operations).
+// Lanes are re-armed only when REARM_MIN of them are idle (or nothing else is running): the
+// set-up code is issued for the whole wave whoever needs it.
+constexpr int REARM_MIN = 12;
+template <bool PRUNE, bool COUNT, bool LDS>
+DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *pts, int lane,
+                            unsigned long long lt_mask, bool hit, V3 pt, float s0, float s1, int hi, int lo,
+                            Counters &cn) {
+  const unsigned long long hm = __ballot(hit);
+  const int nhit = __popcll(hm);
+  if (!P.has_root || nhit == 0) return 0;
+  const int slot = __popcll(hm & lt_mask);
+  if (hit) {
+    pts[0 * 64 + slot] = __float_as_uint(pt.x);
+    pts[1 * 64 + slot] = __float_as_uint(pt.y);
+    pts[2 * 64 + slot] = __float_as_uint(pt.z);
+    pts[3 * 64 + slot] = __float_as_uint(s0);
+    pts[4 * 64 + slot] = __float_as_uint(s1);
+    pts[5 * 64 + slot] = 0u;
+  }
+  __threadfence_block();  // other lanes of this wave read them
+  const int n_items = nhit * (hi - lo);
+  const float inv_nhit = 1.0f / (float)nhit;
+  int next_item = 0;  // wave-uniform
+  int cur = STOP, sp = 0, owner = 0, bit = 0;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+  float tlimit = 0.0f;
+  RayDiv rd;
+  rd.rx = rd.ry = rd.rz = 1.0f;
+  rd.safe = true;
+  for (;;) {
+    const unsigned long long idle = __ballot(cur == STOP);
+    const int remaining = n_items - next_item;
+    if (remaining > 0 && (~idle == 0ull || __popcll(idle) >= REARM_MIN)) {
+      const int rank = __popcll(idle & lt_mask);
+      if (cur == STOP && rank < remaining) {
+        const int k = next_item + rank;
+        int lg = (int)((float)k * inv_nhit);  // k / nhit, k < 2048: off by one at most
+        if (lg * nhit > k) --lg;
+        if ((lg + 1) * nhit <= k) ++lg;
+        owner = k - lg * nhit;
+        bit = hi - 1 - lg - lo;
+        o = mk(__uint_as_float(pts[0 * 64 + owner]), __uint_as_float(pts[1 * 64 + owner]),
+               __uint_as_float(pts[2 * 64 + owner]));
+        light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
+                  tlimit);
+        rd = make_raydiv(P, o, d);
+        sp = 0;
+        cur = 0;
+      }
+      const int armed = __popcll(idle);
+      next_item += armed < remaining ? armed : remaining;
+    }
+    if (__ballot(cur != STOP) == 0ull) break;
+    const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
+    while (cur >= 0) {
+      DIV_COUNT(cn, 2);
+      node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, tlimit, cur, sp, cn);
+    }
+    if (cur != STOP) {
+      DIV_COUNT(cn, 3);
+      float bt = tlimit;
+      int bp = -1;
+      leaf_step<true, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, bt, bp, cur, sp, cn);
+      if (bp >= 0) atomicOr(&pts[5 * 64 + owner], 1u << bit);
+    }
+  }
+  __threadfence_block();
+  return hit ? pts[5 * 64 + slot] : 0u;
 }
 
 // Leaf-list traversal for tiny scenes (<= FLAT_MAX leaves, scene in LDS).  On the exact-
@@ -564,8 +682,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         reinterpret_cast<float4 *>(lds + rec_words + mat_words)[i] = P.leaves[i];
     __syncthreads();
   }
-  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
-  unsigned *cnt = stack + P.stack_depth * 64 + TAG_SLOTS;  // cnt[L], L = 2..max_depth : rays queued at level L
+  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + POINT_WORDS + 32);
+  unsigned *pts = stack + P.stack_depth * 64;  // shaded points of the step (shadow_lights)
+  unsigned *cnt = pts + POINT_WORDS;           // cnt[L], L = 2..max_depth : rays queued at level L
 
   float *Q = P.scratch + gwave * P.scratch_stride;
   long long *acc = P.acc;  // [n_local_pixels][3] fixed point
@@ -727,14 +846,35 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
     // exactly that order.
     if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
+    if (P.n_lights > 1) {
+      // several lights: all shadow rays of the point first (lanes run ahead of each other
+      // through the light list), then the lit terms in the reference's order
+      for (int hi = P.n_lights; hi > 0; hi -= 32) {
+        const int lo = hi > 32 ? hi - 32 : 0;
+        PH_MARK(2);
+        const unsigned occluded = shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, hi, lo, cn);
+        PH_MARK(3);
+        n_shadow += __popcll(__ballot(hit)) * (hi - lo);
+        for (int li = hi - 1; li >= lo; --li) {
+          if (hit && !((occluded >> (li - lo)) & 1u)) {
+            V3 l_dir;
+            float max_d;
+            light_ray(P, li, pt, s0, s1, l_dir, max_d);
+            V3 l_c = ld3(P.lights + (size_t)li * 12 + 9);
+            float s = hs_max(0.0f, dot(l_dir, n));
+            V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
+            V3 h = normalize(add(v, l_dir));
+            float pw = powf(hs_max(0.0f, dot(n, h)), M[6]);
+            V3 spec_c = cscale(cmul(l_c, ld3(M + 3)), pw);
+            clr = add(add(diffuse_c, spec_c), clr);
+          }
+        }
+      }
+    } else
     for (int li = P.n_lights - 1; li >= 0; --li) {
-      const float *Lp = P.lights + (size_t)li * 12;
-      V3 l_a = ld3(Lp + 3), l_b = ld3(Lp + 6);
-      V3 l_pt = add(ld3(Lp + 0), add(mk(l_a.x * s0, l_a.y * s0, l_a.z * s0),
-                                     mk(l_b.x * s1, l_b.y * s1, l_b.z * s1)));  // :96
-      V3 l = subt(l_pt, pt);
-      V3 l_dir = normalize(l);
-      float max_d = magnitude(l);
+      V3 l_dir;
+      float max_d;
+      light_ray(P, li, pt, s0, s1, l_dir, max_d);
       float st;
       int sprim;
       PH_MARK(2);
@@ -742,7 +882,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       PH_MARK(3);
       n_shadow += __popcll(__ballot(hit));
       if (hit && sprim < 0) {
-        V3 l_c = ld3(Lp + 9);
+        V3 l_c = ld3(P.lights + (size_t)li * 12 + 9);
         float s = hs_max(0.0f, dot(l_dir, n));
         V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
         V3 h = normalize(add(v, l_dir));
@@ -876,6 +1016,12 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   }  // scheduling loop
 
   // ---- statistics --------------------------------------------------------------------
+#ifdef RT_PROFILE_PHASES
+  for (int i = 0; i < 4; ++i) {
+    atomicAdd(&P.stats[65536 + 16 + 16 + i], cn.iters[i]);
+    atomicAdd(&P.stats[65536 + 16 + 20 + i], cn.lanes[i]);
+  }
+#endif
   if (lane == 0) {
     unsigned long long life = wall_clock64() - wave_t0;  // 100 MHz ticks (diagnostics)
     atomicAdd(&P.stats[0], n_primary);
@@ -896,6 +1042,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     for (int i = 0; i < 12; ++i) atomicAdd(&P.stats[65536 + 16 + i], ph_acc[i]);
     atomicAdd(&P.stats[65536 + 16 + 12], ph_steps);
     atomicAdd(&P.stats[65536 + 16 + 13], ph_lanes);
+
 #endif
   }
   if (COUNT) {
@@ -929,7 +1076,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
   __shared__ unsigned hist[PROBE_CLASSES];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + TAG_SLOTS + 32);
+  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + POINT_WORDS + 32);
   if (threadIdx.x < PROBE_CLASSES) hist[threadIdx.x] = 0;
   __syncthreads();
   const int span = P.probe_span;  // packets per block (multiple of 64)

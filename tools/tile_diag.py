@@ -42,7 +42,7 @@ for wl in sys.argv[1:] or ["c2"]:
     slow = np.argsort(end)[-6:]
     print('   slowest waves (rays, steps, dry us, end us):', [(int(wd[i,1]), int(steps[i]), int(dry[i]), int(end[i])) for i in slow],
           ' median wave (rays, steps):', int(np.median(wd[:,1])), int(np.median(steps)))
-    ph = r.wave_diag(16384 + 4)[16384:].reshape(-1).astype(float)
+    ph = r.wave_diag(16384 + 8)[16384:].reshape(-1).astype(float)
     if ph[:6].sum() > 0:
         names = ["pop/other", "closest traversal", "shade (direct)", "shadow traversal", "accumulate", "emit bounces",
                  "level select", "packet decode", "samples+getRay", "fetch next packet", "-", "-"]
@@ -50,5 +50,8 @@ for wl in sys.argv[1:] or ["c2"]:
         ph[10] = ph[11] = 0
         tot = ph[:12].sum()
         print("   phases (share of summed wave cycles): " + "  ".join(f"{n} {100*v/tot:.1f}%" for n, v in zip(names, ph[:12]) if v))
+        for nm, i in (("closest node", 0), ("closest leaf", 1), ("shadow node", 2), ("shadow leaf", 3)):
+            lane_it, wave_it = ph[16 + i], ph[20 + i] / 2.0**20
+            print(f"   {nm} iterations: {wave_it/max(1,ph[12]):.1f} per scheduling step, {lane_it/max(1,wave_it):.1f} lanes in each")
         print(f"   steps {int(ph[12])}  avg active lanes/step {ph[13]/max(1,ph[12]):.1f}  cycles/step/wave {tot/max(1,ph[12]):.0f}")
     r.close()
