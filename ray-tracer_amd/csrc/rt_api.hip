@@ -66,6 +66,7 @@ struct rt_ctx {
   int grid_div = 1;                // RT_GRID_DIV: launch 1/grid_div of the resident capacity
   int batches = 0;                 // RT_BATCHES
   int refr_cap = 0, refl_cap = 0;  // RT_REFR_CAP / RT_REFL_CAP (0 = default)
+  int rearm_min = 0;               // RT_REARM_MIN (0 = default)
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
 };
 
@@ -401,6 +402,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   }
   p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 1;  // measured: 1/1 never worse on the small scenes, c3 (mesh) 28.8 -> 21.7 ms
   p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 1;
+  p.rearm_min = c->rearm_min > 0 ? std::min(c->rearm_min, 64) : 12;
   p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
@@ -478,6 +480,7 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_BATCHES")) c->batches = std::atoi(e);
   if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
+  if (const char *e = std::getenv("RT_REARM_MIN")) c->rearm_min = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&

@@ -83,6 +83,7 @@ struct RenderParams {
   int n_leaves, pad4;
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
+  int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
 };
 
 struct LaunchCfg {

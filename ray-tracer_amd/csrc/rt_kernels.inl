@@ -354,9 +354,8 @@ DEVI void light_ray(const RenderParams &P, int li, V3 pt, float s0, float s1, V3
 // occluded ray ORs its bit into the owner's mask in LDS.  The answers are per-ray facts: who
 // computes them, and in which order, cannot change them (the light ray is recomputed from
 // the same operands by the same operations).
-// Lanes are re-armed only when REARM_MIN of them are idle (or nothing else is running): the
+// Lanes are re-armed only when P.rearm_min of them are idle (or nothing else is running): the
 // set-up code is issued for the whole wave whoever needs it.
-constexpr int REARM_MIN = 12;
 template <bool PRUNE, bool COUNT, bool LDS>
 DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *pts, int lane,
                             unsigned long long lt_mask, bool hit, V3 pt, float s0, float s1, int hi, int lo,
@@ -386,7 +385,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   for (;;) {
     const unsigned long long idle = __ballot(cur == STOP);
     const int remaining = n_items - next_item;
-    if (remaining > 0 && (~idle == 0ull || __popcll(idle) >= REARM_MIN)) {
+    if (remaining > 0 && (~idle == 0ull || __popcll(idle) >= P.rearm_min)) {
       const int rank = __popcll(idle & lt_mask);
       if (cur == STOP && rank < remaining) {
         const int k = next_item + rank;
