@@ -405,13 +405,15 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       const int armed = __popcll(idle);
       next_item += armed < remaining ? armed : remaining;
     }
-    if (__ballot(cur != STOP) == 0ull) break;
+    const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
+    if ((at_node | at_leaf) == 0) break;
     const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
-    while (cur >= 0) {
-      DIV_COUNT(cn, 2);
-      node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, tlimit, cur, sp, cn);
-    }
-    if (cur != STOP) {
+    if (at_node >= at_leaf) {
+      if (cur >= 0) {
+        DIV_COUNT(cn, 2);
+        node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, tlimit, cur, sp, cn);
+      }
+    } else if (cur < 0 && cur != STOP) {
       DIV_COUNT(cn, 3);
       float bt = tlimit;
       int bp = -1;

@@ -2,13 +2,13 @@
 """Per-frame time of rank 0's share of an N-way partition on ONE GPU, for the three pipelining
 modes DistributedFrame chooses between (1 frame in flight; F frames, whole-GPU grids; F frames
 sharing the wave slots).  No collective: compute side of the strong-scaling story only.
-  tools/share_time.py [workload ...]      (N = 1 and 8, F = 2)"""
+  tools/share_time.py [workload ...]      (N = 1 and 8; F frames in flight from env F, default 2)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rt_amd as rt
 from bench import make_world, SEED
-F = 2
+F = int(os.environ.get('F', '2'))
 for wl in (sys.argv[1:] or ["c2"]):
     world = make_world(wl)
     grids = rt.generate_grids(SEED, world.width + 10, world.camera.aa)
