@@ -228,3 +228,34 @@ def test_axis_aligned_rays_take_the_plain_division_path(rt, oracle, renderer):
     assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
     assert (g_ids != rt.HIT_NONE).any()
     check_image(rt, g_rgb, o_rgb)
+
+
+@pytest.mark.parametrize("n_extra,name", [(2, "bench1"), (39, "bench1"), (70, "bench5")])
+def test_many_lights_shadow_pool(rt, oracle, renderer, n_extra, name):
+    """getDirectColor folds over wLights (RayTracer.hs:93-106).  With more than one light the
+    GPU path answers the step's inShadow questions from one pool of shadow rays and keeps the
+    answers in 32-bit masks: cover 3 lights, 40 (two mask chunks) and 71 (three), area lights
+    included (jittered sample points, :96), against the oracle's plain loop."""
+    s = rt.Scene.builtin(name)
+    rng = np.random.default_rng(n_extra)
+    for i in range(n_extra):
+        c = rng.uniform(-25, 25, 3); c[1] = rng.uniform(4, 30)
+        ea = rng.uniform(-3, 3, 3) if i % 3 == 0 else np.zeros(3)
+        eb = rng.uniform(-3, 3, 3) if i % 3 == 0 else np.zeros(3)
+        col = rng.uniform(0.01, 0.06, 3)
+        l = rt.Light((f32 * 3)(*c), (f32 * 3)(*ea), (f32 * 3)(*eb), (f32 * 3)(*col))
+        rt.host_lib().rth_scene_add_light(s._h, C.byref(l))
+    s.build_bvh("sah")
+    assert s.view.n_lights == n_extra + 1
+    cfg = rt.default_config(name)
+    cfg.image_width, cfg.image_height, cfg.anti_aliasing = 56, 40, 4
+    w = rt.config_to_world(cfg, s)
+    for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT),
+                           (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
+        (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 9, gflags, oflags)
+        assert int((g_ids != o_ids).sum()) == 0
+        assert (g_st.rays_total, g_st.rays_shadow) == (o_st.rays_total, o_st.rays_shadow)
+        assert g_st.rays_shadow > 0 and g_st.rays_shadow % (n_extra + 1) == 0
+        check_image(rt, g_rgb, o_rgb)
+        fin = np.isfinite(o_rgb).all(axis=1)
+        assert np.allclose(g_rgb[fin], o_rgb[fin], rtol=2e-5, atol=2e-6)
