@@ -25,10 +25,7 @@ struct rt_ctx {
   std::string err;
 
   // scene
-  float4 *d_nodes = nullptr, *d_prims = nullptr, *d_leaves = nullptr;
-  int n_leaves = 0;
-  int flat_max = 0;  // RT_FLAT_MAX: walk the leaf list instead of the tree up to this many leaves (<= FLAT_MAX).
-                     // Off: parity-green, but at 13 leaves (bench1) 2.80 vs 2.53 ms, equal at 3 leaves; only c1 gains
+  float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
@@ -124,7 +121,6 @@ struct Repack {
   const rt_scene *sc;
   std::vector<float> nodes;  // 16 floats per device node
   std::vector<float> prims;  // 16 floats per record
-  std::vector<float> leaves; // 8 floats per leaf: box, first record, count (depth-first order)
   std::vector<char> seen;
   int max_depth = 0;
   std::string err;
@@ -164,11 +160,6 @@ struct Repack {
       prims.insert(prims.end(), rec, rec + 16);
     }
     put_i(&prims[(size_t)first_rec * 16 + 15], count);
-    float lf[8];
-    std::memcpy(lf, &n.xmin, 24);
-    put_i(lf + 6, first_rec);
-    put_i(lf + 7, count);
-    leaves.insert(leaves.end(), lf, lf + 8);
     return -1 - first_rec;
   }
 
@@ -371,16 +362,12 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.n_materials = c->n_materials;
   cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16 +
                         (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
-  p.leaves = c->d_leaves;
-  p.n_leaves = c->n_leaves;
-  cfg.flat = cfg.prune && c->boxes_safe && c->n_leaves >= 1 && c->n_leaves <= c->flat_max;
-  if (cfg.flat) cfg.lds_scene_bytes += (size_t)c->n_leaves * 32;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
-  if (!cfg.lds_scene) { cfg.lds_scene_bytes = 0; cfg.flat = false; }
+  if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
   cfg.lds_bytes += cfg.lds_scene_bytes;
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.flat, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.flat, cfg.lds_bytes);
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -475,7 +462,6 @@ int rt_init(int device, rt_ctx **out) {
   c->n_cus = prop.multiProcessorCount;
   if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_LDS_SCENE")) c->lds_scene_mode = std::atoi(e);
-  if (const char *e = std::getenv("RT_FLAT_MAX")) c->flat_max = std::min(FLAT_MAX, std::max(0, std::atoi(e)));
   if (const char *e = std::getenv("RT_GRID_DIV")) c->grid_div = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("RT_BATCHES")) c->batches = std::atoi(e);
   if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
@@ -498,7 +484,7 @@ void rt_shutdown(rt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {c->d_leaves, c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
@@ -543,8 +529,6 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   int rc;
   if ((rc = upload(c, &c->d_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
   if ((rc = upload(c, &c->d_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
-  if ((rc = upload(c, &c->d_leaves, rp.leaves.data(), rp.leaves.size() * 4))) return rc;
-  c->n_leaves = (int)(rp.leaves.size() / 8);
   if ((rc = upload(c, &c->d_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
   if ((rc = upload(c, &c->d_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;

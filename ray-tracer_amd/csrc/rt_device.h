@@ -33,7 +33,6 @@ constexpr int NODE_F4 = 4;
 //   i[12] kind (0 sphere, 1 triangle)  i[13] material  i[14] object id
 //   i[15] number of records in this leaf (valid in the leaf's first record)
 constexpr int PRIM_F4 = 4;
-constexpr int FLAT_MAX = 16;   // most leaves for the leaf-list traversal
 constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)
 
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
@@ -79,8 +78,6 @@ struct RenderParams {
   int *order;                            // ticket -> (packet << 7) | code, cost-sorted
   int probe_blocks, probe_span;          // blocks and packets per block (multiple of 256)
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
-  const float4 *leaves;                  // [n_leaves][2]: box (6 floats), first record, count (depth-first)
-  int n_leaves, pad4;
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
@@ -92,15 +89,14 @@ struct LaunchCfg {
   bool prune, count;
   hipEvent_t ev_k0, ev_k1;  // recorded right before / after render_kernel (may be null)
   bool lds_scene;           // render from the block's LDS copy of the scene
-  bool flat;                // ... and walk the leaf list instead of the tree (tiny scenes)
   size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
 };
 
 // one per arithmetic mode (separate translation units, different -ffp-contract)
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
-int occupancy_strict(bool prune, bool count, bool lds_scene, bool flat, size_t lds_bytes);
-int occupancy_fma(bool prune, bool count, bool lds_scene, bool flat, size_t lds_bytes);
+int occupancy_strict(bool prune, bool count, bool lds_scene, size_t lds_bytes);
+int occupancy_fma(bool prune, bool count, bool lds_scene, size_t lds_bytes);
 
 inline size_t lds_bytes_for(int stack_depth) {
   return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + POINT_WORDS + 32) * 4;

@@ -425,72 +425,6 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   return hit ? pts[5 * 64 + slot] : 0u;
 }
 
-// Leaf-list traversal for tiny scenes (<= FLAT_MAX leaves, scene in LDS).  On the exact-
-// quotient path a leaf's box test implies the box tests of all its ancestors (a child box lies
-// inside its parent's, subtraction, the quotient and max/min are monotone, no NaN can occur),
-// so hitBVH's candidate set is exactly "the primitives of the leaves whose OWN box the line
-// hits": the inner nodes only ever cull.  With a dozen leaves it is cheaper to test every leaf
-// box than to walk the tree: the loop is wave-uniform (no per-lane stack, no divergence between
-// lanes that sit in different subtrees, no dependent pop -> fetch -> test chain), the box data
-// are the same LDS words for all lanes (broadcast reads), and the wave as a whole visits
-// fewer boxes than the union of its lanes' tree paths.  Leaves are listed in depth-first order,
-// so the tie rule (larger record index wins on equal t) is unchanged.
-template <bool ANY, bool PRUNE>
-DEVI void traverse_flat(const RenderParams &P, const float4 *sc, const float4 *leaves, bool active, V3 o, V3 d,
-                        const RayDiv &rd, float tlimit, float &best_t, int &best_p) {
-  best_t = ANY ? tlimit : INFINITY;
-  best_p = -1;
-  bool live = active;
-  for (int i = 0; i < P.n_leaves; ++i) {
-    const float4 b0 = leaves[2 * i], b1 = leaves[2 * i + 1];
-    float entry, exit_;
-    bool h = hits_box<true>(o, d, rd, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, entry, exit_) && live;
-    if (PRUNE) h = h && !(entry > prune_limit(best_t) || exit_ < BEHIND);
-    if (__ballot(h) == 0ull) continue;
-    const int first = __float_as_int(b1.z), count = __float_as_int(b1.w);
-    for (int k = 0; k < count; ++k) {
-      const float4 *q = prim_rec<true>(P, sc, first + k);
-      const float4 q0 = q[0], q1 = q[1], q3 = q[3];
-      float t;
-      bool ok;
-      if (__float_as_int(q3.x) != 0) {  // wave-uniform: every lane looks at the same record
-        const float4 q2 = q[2];
-        ok = hit_triangle(o, d, q0, q1, q2, t);
-      } else {
-        ok = hit_sphere(o, d, q0, q1.x, t);
-      }
-      ok = ok && h;
-      if (ANY) {
-        if (ok && t < tlimit) {
-          best_t = t;
-          best_p = first + k;
-          live = false;
-          h = false;
-        }
-      } else if (ok && (t < best_t || (t == best_t && first + k > best_p))) {
-        best_t = t;
-        best_p = first + k;
-      }
-    }
-    if (ANY && __ballot(live) == 0ull) break;
-  }
-}
-
-// hitBVH for one wave of rays: the leaf list when the build has one and every lane is on the
-// exact-quotient path, the tree otherwise.
-template <bool ANY, bool PRUNE, bool COUNT, bool LDS, bool FLAT>
-DEVI void trace(const RenderParams &P, const float4 *sc, const float4 *leaves, unsigned *stack, int lane,
-                bool active, V3 o, V3 d, float tlimit, float &best_t, int &best_p, Counters &cn) {
-  if (FLAT) {
-    const RayDiv rd = make_raydiv(P, o, d);
-    if (__ballot(active && !rd.safe) == 0ull) {
-      traverse_flat<ANY, PRUNE>(P, sc, leaves, active, o, d, rd, tlimit, best_t, best_p);
-      return;
-    }
-  }
-  traverse<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, active, o, d, tlimit, best_t, best_p, cn);
-}
-
 // reflect / refract / orthonormal (RayTracer.hs:162-179, 453-459)
 DEVI V3 reflect(V3 dir, V3 n) { return subt(dir, multiply(n, 2 * dot(dir, n))); }
 DEVI bool refract(V3 dir, V3 normal, float nt, V3 &t_out) {
@@ -652,7 +586,7 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
   }
 }
 
-template <bool PRUNE, bool COUNT, bool LDS, bool FLAT>
+template <bool PRUNE, bool COUNT, bool LDS>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
   extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
@@ -664,9 +598,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
   const int rec_words = LDS ? (P.n_node_recs + P.n_prim_recs) * LDS_REC_F4 * 4 : 0;
   const int mat_words = LDS ? ((P.n_materials * 12 + 3) & ~3) : 0;
-  const int scene_words = rec_words + mat_words + (FLAT ? P.n_leaves * 8 : 0);
+  const int scene_words = rec_words + mat_words;
   const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
-  const float4 *ldsLeaves = reinterpret_cast<const float4 *>(lds + rec_words + mat_words);
   if (LDS) {
     // the block's one and only barrier: stage the scene (a few KB) once per persistent block
     float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -678,9 +611,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       dst[(size_t)rec * LDS_REC_F4 + part] = v;
     }
     for (int i = threadIdx.x; i < P.n_materials * 12; i += 256) lds[rec_words + i] = __float_as_uint(P.materials[i]);
-    if (FLAT)
-      for (int i = threadIdx.x; i < P.n_leaves * 2; i += 256)
-        reinterpret_cast<float4 *>(lds + rec_words + mat_words)[i] = P.leaves[i];
     __syncthreads();
   }
   unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + POINT_WORDS + 32);
@@ -810,7 +740,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // ---- raytrace (RayTracer.hs:55-71): closest hit ----------------------------------
     float t;
     int p;
-    trace<false, PRUNE, COUNT, LDS, FLAT>(P, sc, ldsLeaves, stack, lane, active, o, d, 0.0f, t, p, cn);
+    traverse<false, PRUNE, COUNT, LDS>(P, sc, stack, lane, active, o, d, 0.0f, t, p, cn);
     const bool hit = active && p >= 0;
     PH_MARK(1);
     n_hits += __popcll(__ballot(hit));
@@ -879,7 +809,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       float st;
       int sprim;
       PH_MARK(2);
-      trace<true, PRUNE, COUNT, LDS, FLAT>(P, sc, ldsLeaves, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
       PH_MARK(3);
       n_shadow += __popcll(__ballot(hit));
       if (hit && sprim < 0) {
@@ -1224,12 +1154,10 @@ __global__ void resolve_kernel(const RenderParams P) {
 
 template <bool PRUNE, bool COUNT>
 static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
-  if (cfg.lds_scene && cfg.flat && PRUNE && !COUNT)
-    hipLaunchKernelGGL((render_kernel<true, false, true, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
-  else if (cfg.lds_scene && !COUNT)
-    hipLaunchKernelGGL((render_kernel<PRUNE, false, true, false>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
+  if (cfg.lds_scene && !COUNT)
+    hipLaunchKernelGGL((render_kernel<PRUNE, false, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
   else
-    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false, false>), dim3(cfg.grid), dim3(cfg.block),
+    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false>), dim3(cfg.grid), dim3(cfg.block),
                        cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
 }
 
@@ -1258,20 +1186,18 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, bool flat, size_t lds_bytes) {
+static int occupancy(bool prune, bool count, bool lds_scene, size_t lds_bytes) {
   int n = 0;
   hipError_t e;
-  if (lds_scene && flat && prune && !count) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true>, 256, lds_bytes);
-  } else if (lds_scene && !count) {
-    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true, false>, 256, lds_bytes);
+  if (lds_scene && !count) {
+    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true>, 256, lds_bytes);
   } else if (prune) {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, false>, 256, lds_bytes);
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false>, 256, lds_bytes);
   } else {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false, false>, 256, lds_bytes);
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false>, 256, lds_bytes);
   }
   return e == hipSuccess ? n : 0;
 }
