@@ -129,11 +129,14 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--flags", type=int, default=0, help="rt_render flags (1 = FMA build)")
-    ap.add_argument("--frames-in-flight", type=int, default=2)
+    ap.add_argument("--frames-in-flight", type=int, default=3)
     ap.add_argument("--share-gpu", default="auto", choices=["auto", "yes", "no"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="self-test: run the gather/assemble path with one rank and check the frame")
+    ap.add_argument("--rehearse-share", default=None, metavar="R/N",
+                    help="one-GPU timing rehearsal of rank R's share of an N-rank job (no collective); "
+                         "the line then reports that share's rays only")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,7 +167,9 @@ def main() -> None:
     # F contexts render alternate frames on their own streams (ray-tracer_amd/distributed.py):
     # the next frame's blocks fill the wave slots the current frame's tail leaves empty
     df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight,
-                              force_collective=args.force_collective, share_gpu=args.share_gpu)
+                              force_collective=args.force_collective, share_gpu=args.share_gpu,
+                              rehearse_share=tuple(int(x) for x in args.rehearse_share.split("/"))
+                              if args.rehearse_share else None)
 
     def fence():
         df.finish()
@@ -218,10 +223,12 @@ def main() -> None:
                        "rays_per_frame": int(rays_frame),
                        "rays_primary": int(rays[1].item()), "rays_shadow": int(rays[2].item()),
                        "rays_bounce": int(rays[3].item()),
-                       "frames_in_flight": df.mode[0], "contexts_share_wave_slots": df.mode[1],
+                       "frames_in_flight": df.mode[0], "grid_fraction_per_context": f"1/{df.mode[1]}",
                        "parallelism": f"tiles%{world_size}" + ("+rccl_gather" if world_size > 1 else ""),
                        "sample_seed": SEED},
         }
+        if args.rehearse_share:
+            out["config"]["rehearsal_of_rank_share"] = args.rehearse_share
     if args.force_collective:
         ref = torch.zeros_like(df.frames[0])
         df.r.set_partition(0, 1)
@@ -231,7 +238,7 @@ def main() -> None:
         out["config"]["collective_path_frame_identical"] = bool(same)
         if not same:
             raise SystemExit("gathered + assembled frame differs from the directly rendered one")
-    if world_size == 1 and not args.force_collective:
+    if world_size == 1 and not args.force_collective and not args.rehearse_share:
         # Roofline of the dominant kernel.  Its launch duration is measured with HIP events
         # recorded by the library on the launch stream right around render_kernel
         # (rt_stats.ms_kernel), one frame in flight, averaged over `steps` launches -- the

@@ -364,10 +364,11 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
                         (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
+  cfg.mlight = c->n_lights > 1;
   cfg.lds_bytes += cfg.lds_scene_bytes;
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.lds_bytes);
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

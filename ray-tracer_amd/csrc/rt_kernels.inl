@@ -586,7 +586,7 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
   }
 }
 
-template <bool PRUNE, bool COUNT, bool LDS>
+template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
   extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
@@ -642,11 +642,15 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
   for (;;) {
     // ---- choose what to run: deepest full queue, else the next chunk of primaries,
-    //      else the deepest non-empty queue -------------------------------------------
+    //      else (drain, no packets left) the SHALLOWEST non-empty queue: its children top
+    //      up the next level before that level gets its one partial step, so a drain costs
+    //      at most one partial step per level (deepest-first revisits every deeper level
+    //      after each shallower one).  No queue can overflow: without a full level every
+    //      level holds < 64 rays and a step adds at most 128 to the next (QCAP = 192).
     int level = 0;
     if (full_mask) level = 31 - __clz((int)full_mask);
     else if (cur_packet >= 0) level = 1;
-    else if (nonempty_mask) level = 31 - __clz((int)nonempty_mask);
+    else if (nonempty_mask) level = __ffs((int)nonempty_mask) - 1;
     level = wave_uniform(level);
     if (level == 0) break;
     ++n_steps;
@@ -777,8 +781,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
     // exactly that order.
     if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
-    if (P.n_lights > 1) {
-      // several lights: all shadow rays of the point first (lanes run ahead of each other
+    if (MLIGHT) {
+      // several lights (the host picks this build for them): all shadow rays of the point first (lanes run ahead of each other
       // through the light list), then the lit terms in the reference's order
       for (int hi = P.n_lights; hi > 0; hi -= 32) {
         const int lo = hi > 32 ? hi - 32 : 0;
@@ -1154,10 +1158,16 @@ __global__ void resolve_kernel(const RenderParams P) {
 
 template <bool PRUNE, bool COUNT>
 static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
-  if (cfg.lds_scene && !COUNT)
-    hipLaunchKernelGGL((render_kernel<PRUNE, false, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
+  if (cfg.mlight && PRUNE && !COUNT) {
+    if (cfg.lds_scene)
+      hipLaunchKernelGGL((render_kernel<true, false, true, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
+    else
+      hipLaunchKernelGGL((render_kernel<true, false, false, true>), dim3(cfg.grid), dim3(cfg.block),
+                         cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
+  } else if (cfg.lds_scene && !COUNT)
+    hipLaunchKernelGGL((render_kernel<PRUNE, false, true, false>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
   else
-    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false>), dim3(cfg.grid), dim3(cfg.block),
+    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false, false>), dim3(cfg.grid), dim3(cfg.block),
                        cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
 }
 
@@ -1186,18 +1196,21 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, size_t lds_bytes) {
+static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, size_t lds_bytes) {
   int n = 0;
   hipError_t e;
-  if (lds_scene && !count) {
-    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true>, 256, lds_bytes);
+  if (mlight && prune && !count) {
+    if (lds_scene) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, true>, 256, lds_bytes);
+  } else if (lds_scene && !count) {
+    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true, false>, 256, lds_bytes);
   } else if (prune) {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false>, 256, lds_bytes);
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, false>, 256, lds_bytes);
   } else {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false>, 256, lds_bytes);
+    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false, false>, 256, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false, false>, 256, lds_bytes);
   }
   return e == hipSuccess ? n : 0;
 }

@@ -53,18 +53,24 @@ class DistributedFrame:
     After `finish()`, rank 0 holds the newest frames in `self.frames` ([H*W*3] float32 each,
     render's pixel order)."""
 
-    def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 2,
-                 force_collective: bool = False, share_gpu: str = "auto"):
-        """share_gpu: "auto" times a few frames at start-up and keeps the fastest of
-        {1 frame in flight; `in_flight` frames, whole-GPU grids; `in_flight` frames, each
-        context launching 1/in_flight of the wave slots (rt_set_concurrency)} -- which one wins
-        depends on the frame's size and on how the runtime maps the contexts' streams onto
-        hardware queues; "yes" / "no" force the choice."""
+    def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 3,
+                 force_collective: bool = False, share_gpu: str = "auto",
+                 rehearse_share: Optional[Tuple[int, int]] = None):
+        """rehearse_share=(r, n): timing rehearsal on one GPU of what rank r of an n-rank job
+        computes (its tiles only, no collective, the frame buffers then hold compact tiles).
+        in_flight: the most contexts (frames in flight) to use.  share_gpu: "auto" times a few
+        frames at start-up for a handful of (frames in flight F, grid fraction 1/d) pairs -- each
+        context launches 1/d of the GPU's wave slots (rt_set_concurrency) -- and keeps the
+        fastest; which one wins depends on the frame's size (a small share of a frame wants
+        fewer, longer-lived waves: less start-up and queue-drain cost per ray) and on how the
+        runtime maps the contexts' streams onto hardware queues.  "yes" forces (in_flight,
+        1/in_flight), "no" (in_flight, whole GPU).  The choice never changes a pixel."""
         self.rank, self.nranks, self.device = rank, nranks, device
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
+        self.rehearsal = rehearse_share is not None
         for r in self.renderers:
-            r.set_partition(rank, nranks)
+            r.set_partition(*(rehearse_share if self.rehearsal else (rank, nranks)))
         self.mode = self._choose_mode(share_gpu)
         self.r = self.renderers[0]
         til = self.r.tiling()
@@ -93,22 +99,25 @@ class DistributedFrame:
         self.asm_done = [None] * self.depth
 
     def _choose_mode(self, share_gpu: str):
-        """(frames in flight, contexts share the wave slots) -- local timing only, no collective."""
+        """(frames in flight, grid divisor) -- local timing only, no collective."""
         if self.depth == 1:
-            return (1, False)
+            return (1, 1)
         if share_gpu in ("yes", "no"):
-            share = share_gpu == "yes"
+            div = self.depth if share_gpu == "yes" else 1
             for r in self.renderers:
-                r.set_concurrency(self.depth if share else 1)
-            return (self.depth, share)
+                r.set_concurrency(div)
+            return (self.depth, div)
         import time
         w = self.renderers[0].world
         scratch = [torch.zeros(w.height * w.width * 3 + 4096, dtype=torch.float32, device=self.device)
                    for _ in range(self.depth)]
+        candidates = [(1, 1)]
+        for f in range(2, self.depth + 1):
+            candidates += [(f, 1), (f, f - 1), (f, f)] if f > 2 else [(f, 1), (f, f)]
         best = None
-        for depth, share in ((1, False), (self.depth, False), (self.depth, True)):
+        for depth, div in candidates:
             for r in self.renderers:
-                r.set_concurrency(depth if share else 1)
+                r.set_concurrency(div)
             times = []
             for rep in range(3):
                 torch.cuda.synchronize(self.device)
@@ -120,12 +129,12 @@ class DistributedFrame:
                 times.append(time.perf_counter() - t0)
             t = min(times[1:])
             if best is None or t < best[0] * 0.98:   # prefer the simpler mode unless 2 % faster
-                best = (t, depth, share)
-        _, depth, share = best
+                best = (t, depth, div)
+        _, depth, div = best
         for r in self.renderers:
-            r.set_concurrency(depth if share else 1)
+            r.set_concurrency(div)
         self.depth = depth
-        return (depth, share)
+        return (depth, div)
 
     @property
     def frame(self):
@@ -141,7 +150,10 @@ class DistributedFrame:
         if world is not None:
             r.set_world(world)
         if not self.collective:
-            r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
+            if self.rehearsal:
+                r.render_tiles_async(self.frames[slot].data_ptr(), flags, rs.cuda_stream)
+            else:
+                r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
             self.k += 1
             return
         with torch.cuda.stream(rs):
