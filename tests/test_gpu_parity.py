@@ -259,3 +259,52 @@ def test_many_lights_shadow_pool(rt, oracle, renderer, n_extra, name):
         check_image(rt, g_rgb, o_rgb)
         fin = np.isfinite(o_rgb).all(axis=1)
         assert np.allclose(g_rgb[fin], o_rgb[fin], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,rpp,depth", [("bench1", 16, 6), ("bench5", 64, 6)])
+def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth):
+    """BASELINE.json's full size (1920x1080; configs[1] = bench1 at 16 spp, configs[3] = the
+    glossy scene at 64 spp), where the oracle needs minutes for a whole frame: size-independent
+    properties instead -- the frame is bitwise reproducible, identical for an 8-way tile
+    partition, the ray accounting closes (render maps colorPixel over W*H pixels x aa^2 samples,
+    RayTracer.hs:18-23; one inShadow ray per light and shaded hit, :93-100), and stripes of
+    rows spread over the frame match the oracle's rendering of the same rows to the parity bar
+    (ids bit-exact, 8-bit |delta| <= 1, PSNR >= 50 dB)."""
+    import torch
+    W, H = 1920, 1080
+    w = make_world(rt, name, W, H, rpp, depth=depth, view=(16, 9, 10))
+    grids = rt.generate_grids(77, W + 10, w.camera.aa)
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    a_rgb, a_ids, a_st = renderer.render(0, want_hit_ids=True)
+    b_rgb, _, b_st = renderer.render(0)
+    assert np.array_equal(a_rgb.view(np.uint32), b_rgb.view(np.uint32))
+    assert a_st.rays_total == b_st.rays_total
+    assert a_st.rays_primary == W * H * w.spp
+    assert a_st.rays_shadow == a_st.shaded_hits * w.scene.view.n_lights
+    assert a_st.primary_hits == int((a_ids != rt.HIT_NONE).sum())
+    # 8 virtual ranks, gathered layout, assembled
+    n = 8
+    til = renderer.tiling()
+    stride = ((til.n_tiles + n - 1) // n) * til.tile_w * til.tile_h * 3
+    gathered = torch.zeros(n * stride, dtype=torch.float32, device="cuda:0")
+    rays = 0
+    for r in range(n):
+        renderer.set_partition(r, n)
+        renderer.render_tiles_async(gathered.data_ptr() + r * stride * 4)
+        rays += renderer.collect().rays_total
+    out = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+    renderer.set_partition(0, n)
+    renderer.assemble_async(gathered.data_ptr(), n, stride, out.data_ptr())
+    renderer.collect()
+    renderer.set_partition(0, 1)
+    assert rays == a_st.rays_total
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(-1, 3), a_rgb.view(np.uint32))
+    # stripes against the oracle
+    n_rows = 2 if rpp > 16 else 4
+    for r0 in (0, H // 3, (2 * H) // 3 + 1, H - n_rows):
+        o_rgb, o_ids, _ = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT, rows=(r0, r0 + n_rows))
+        sl = slice(r0 * W, (r0 + n_rows) * W)
+        assert int((a_ids[sl] != o_ids[sl]).sum()) == 0
+        check_image(rt, a_rgb[sl], o_rgb[sl])
