@@ -169,7 +169,9 @@ def main() -> None:
     df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight,
                               force_collective=args.force_collective, share_gpu=args.share_gpu,
                               rehearse_share=tuple(int(x) for x in args.rehearse_share.split("/"))
-                              if args.rehearse_share else None)
+                              if args.rehearse_share else None,
+                              tune_worlds=(lambda k: make_world(args.workload, float(k)))
+                              if WORKLOADS[args.workload][1] is None else None)
 
     def fence():
         df.finish()

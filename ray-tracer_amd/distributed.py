@@ -55,9 +55,11 @@ class DistributedFrame:
 
     def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 3,
                  force_collective: bool = False, share_gpu: str = "auto",
-                 rehearse_share: Optional[Tuple[int, int]] = None):
+                 rehearse_share: Optional[Tuple[int, int]] = None, tune_worlds=None):
         """rehearse_share=(r, n): timing rehearsal on one GPU of what rank r of an n-rank job
         computes (its tiles only, no collective, the frame buffers then hold compact tiles).
+        tune_worlds: callable k -> World for jobs that upload a new scene per frame (animation);
+        the start-up timing then does the same, since the upload serialises a context's frames.
         in_flight: the most contexts (frames in flight) to use.  share_gpu: "auto" times a few
         frames at start-up for a handful of (frames in flight F, grid fraction 1/d) pairs -- each
         context launches 1/d of the GPU's wave slots (rt_set_concurrency) -- and keeps the
@@ -69,6 +71,7 @@ class DistributedFrame:
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
         self.rehearsal = rehearse_share is not None
+        self.tune_worlds = tune_worlds
         for r in self.renderers:
             r.set_partition(*(rehearse_share if self.rehearsal else (rank, nranks)))
         self.mode = self._choose_mode(share_gpu)
@@ -124,6 +127,8 @@ class DistributedFrame:
                 t0 = time.perf_counter()
                 for k in range(2 * self.depth):
                     j = k % depth
+                    if self.tune_worlds is not None:
+                        self.renderers[j].set_world(self.tune_worlds(k))
                     self.renderers[j].render_tiles_async(scratch[j].data_ptr(), 0, 0)
                 torch.cuda.synchronize(self.device)
                 times.append(time.perf_counter() - t0)
