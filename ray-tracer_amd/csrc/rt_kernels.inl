@@ -492,6 +492,17 @@ DEVI long long to_fixed(float c) {
   return (long long)(c * 1099511627776.0f);
 }
 
+// Data-parallel-primitive move of a 64-bit value: lane i receives the value of the lane that
+// `CTRL` names (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143), 0 when that
+// lane does not exist or the lane's row is not in ROW_MASK.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK = 0xF>
+DEVI long long dpp_mov64(long long v) {
+  int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
 // Packet fetch.  PACKET_SHARDS ticket counters (one 128-B line each); ticket i of shard
 // sh is entry i * PACKET_SHARDS + sh of the cost-sorted packet order.  A wave takes a BATCH of ids per atomic (one L2
 // round trip per batch instead of per 64 rays); the batch shrinks towards the end of
@@ -837,21 +848,48 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
       const bool contrib = (level == 1) ? active : hit;
       long long cr = contrib ? to_fixed(c.x) : 0, cg = contrib ? to_fixed(c.y) : 0,
                 cb = contrib ? to_fixed(c.z) : 0;
-      const unsigned key = contrib ? pix : (0xC0000000u | (unsigned)lane);  // unique when idle
-      const unsigned key_prev = __shfl_up(key, 1);
-      const unsigned key_next = __shfl_down(key, 1);
-      const bool head = (lane == 0) || key_prev != key;
-      const bool tail = contrib && ((lane == 63) || key_next != key);
-      const unsigned long long heads = __ballot(head);
-      // level 1: a pixel's lanes are its spp consecutive samples, runs cannot be longer
-      const int scan_span = (level == 1 && P.spp < 64) ? P.spp : 64;
-      if (~heads) {  // some run is longer than one lane
-        const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        const int start = 63 - __clzll(upto);  // first lane of this lane's run
+      bool tail;
+      if (level == 1 && (P.spp == 4 || P.spp == 16 || P.spp == 64)) {
+        // primaries: a pixel's samples are spp consecutive lanes starting at a multiple of spp,
+        // so the sums run inside (spp 4, 16) or over (spp 64) the 16-lane DPP rows: row shifts
+        // (out-of-row sources read 0) instead of LDS-routed shuffles
+        const int in_run = lane & (P.spp - 1);
+        tail = active && in_run == P.spp - 1;
+        { long long ur = dpp_mov64<0x111>(cr), ug = dpp_mov64<0x111>(cg), ub = dpp_mov64<0x111>(cb);
+          if (in_run >= 1) { cr += ur; cg += ug; cb += ub; } }
+        { long long ur = dpp_mov64<0x112>(cr), ug = dpp_mov64<0x112>(cg), ub = dpp_mov64<0x112>(cb);
+          if (in_run >= 2) { cr += ur; cg += ug; cb += ub; } }
+        if (P.spp >= 16) {
+          { long long ur = dpp_mov64<0x114>(cr), ug = dpp_mov64<0x114>(cg), ub = dpp_mov64<0x114>(cb);
+            cr += ur; cg += ug; cb += ub; }
+          { long long ur = dpp_mov64<0x118>(cr), ug = dpp_mov64<0x118>(cg), ub = dpp_mov64<0x118>(cb);
+            cr += ur; cg += ug; cb += ub; }
+        }
+        if (P.spp == 64) {
+          // lane 15 of each row holds the row's sum: rows 1, 3 add their predecessor's
+          // (row_bcast:15), then rows 2, 3 add lane 31's (row_bcast:31); lane 63 = wave sum
+          { long long ur = dpp_mov64<0x142, 0xA>(cr), ug = dpp_mov64<0x142, 0xA>(cg), ub = dpp_mov64<0x142, 0xA>(cb);
+            cr += ur; cg += ug; cb += ub; }
+          { long long ur = dpp_mov64<0x143, 0xC>(cr), ug = dpp_mov64<0x143, 0xC>(cg), ub = dpp_mov64<0x143, 0xC>(cb);
+            cr += ur; cg += ug; cb += ub; }
+        }
+      } else {
+        const unsigned key = contrib ? pix : (0xC0000000u | (unsigned)lane);  // unique when idle
+        const unsigned key_prev = __shfl_up(key, 1);
+        const unsigned key_next = __shfl_down(key, 1);
+        const bool head = (lane == 0) || key_prev != key;
+        tail = contrib && ((lane == 63) || key_next != key);
+        const unsigned long long heads = __ballot(head);
+        // level 1: a pixel's lanes are its spp consecutive samples, runs cannot be longer
+        const int scan_span = (level == 1 && P.spp < 64) ? P.spp : 64;
+        if (~heads) {  // some run is longer than one lane
+          const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+          const int start = 63 - __clzll(upto);  // first lane of this lane's run
 #pragma unroll
-        for (int dlt = 1; dlt < scan_span; dlt <<= 1) {
-          long long ur = __shfl_up(cr, dlt), ug = __shfl_up(cg, dlt), ub = __shfl_up(cb, dlt);
-          if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
+          for (int dlt = 1; dlt < scan_span; dlt <<= 1) {
+            long long ur = __shfl_up(cr, dlt), ug = __shfl_up(cg, dlt), ub = __shfl_up(cb, dlt);
+            if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
+          }
         }
       }
       // the run's last lane adds the run's sum to the pixel: 64-bit integer atomics without
