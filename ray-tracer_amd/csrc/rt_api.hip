@@ -349,7 +349,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
 
   LaunchCfg cfg{};
   cfg.block = 64 * WAVES_PER_BLOCK;
-  cfg.lds_bytes = lds_bytes_for(c->stack_depth);
+  cfg.mlight = c->n_lights > 1;
+  p.point_words = cfg.mlight ? POINT_WORDS : 0;
+  cfg.lds_bytes = lds_bytes_for(c->stack_depth, p.point_words);
   cfg.ev_k0 = c->evk0;
   cfg.ev_k1 = c->evk1;
   cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
@@ -363,27 +365,35 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16 +
                         (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
+  int wpb = WAVES_PER_BLOCK;
+  if (!cfg.lds_scene && c->lds_scene_mode != 0 && !cfg.count && cfg.prune &&
+      lds_bytes_for(c->stack_depth, p.point_words, 8) + cfg.lds_scene_bytes <= 80 * 1024) {
+    // too big beside four blocks' stacks, but two 8-wave blocks per CU can share one copy each
+    wpb = 8;
+    cfg.block = 512;
+    cfg.lds_bytes = lds_bytes_for(c->stack_depth, p.point_words, 8);
+    cfg.lds_scene = true;
+  }
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
-  cfg.mlight = c->n_lights > 1;
   cfg.lds_bytes += cfg.lds_scene_bytes;
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.lds_bytes);
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.block, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.block, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
-  int want = (p.n_packets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  int want = (p.n_packets + wpb - 1) / wpb;
   cfg.grid = std::max(1, std::min(c->n_cus * per_cu / std::max(1, c->grid_div), want));
-  if (cfg.grid * WAVES_PER_BLOCK > c->scratch_waves)
+  if (cfg.grid * wpb > c->scratch_waves)
     return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
 
   // Refractive packets (a binary ray tree per sample) are handed out pixel by pixel when the
   // rank has few packets per wave: the frame then ends on quarter-size work items.
   p.split_refractive = c->split_mode >= 0 ? c->split_mode
-                                           : (p.n_packets < 48 * cfg.grid * WAVES_PER_BLOCK ? 1 : 0);
+                                           : (p.n_packets < 48 * cfg.grid * wpb ? 1 : 0);
   {
     // a wave should come back for tickets at least ~RT_BATCHES times per frame: its estimate of
     // what is left in the shard is one batch old, and an oversized last batch is the frame's tail
-    int waves_per_shard = std::max(1, cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);
+    int waves_per_shard = std::max(1, cfg.grid * wpb / PACKET_SHARDS);
     int per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
     int batches = c->batches > 0 ? c->batches : 8;
     p.batch_cap = std::min(16, std::max(1, per_shard / (waves_per_shard * batches)));
@@ -391,7 +401,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 1;  // measured: 1/1 never worse on the small scenes, c3 (mesh) 28.8 -> 21.7 ms
   p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 1;
   p.rearm_min = c->rearm_min > 0 ? std::min(c->rearm_min, 64) : 12;
-  p.batch_div = std::max(1, 2 * cfg.grid * WAVES_PER_BLOCK / PACKET_SHARDS);  // 2 x waves per shard
+  p.batch_div = std::max(1, 2 * cfg.grid * wpb / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
   p.probe_blocks = std::max(1, (p.n_packets + p.probe_span - 1) / p.probe_span);

@@ -80,6 +80,7 @@ struct RenderParams {
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
+  int point_words;                       // LDS words per wave for the step's shaded points (POINT_WORDS, or 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
 };
 
@@ -96,11 +97,11 @@ struct LaunchCfg {
 // one per arithmetic mode (separate translation units, different -ffp-contract)
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
-int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, size_t lds_bytes);
-int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, size_t lds_bytes);
+int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes);
+int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes);
 
-inline size_t lds_bytes_for(int stack_depth) {
-  return (size_t)WAVES_PER_BLOCK * (size_t)(stack_depth * 64 + POINT_WORDS + 32) * 4;
+inline size_t lds_bytes_for(int stack_depth, int point_words, int waves_per_block = WAVES_PER_BLOCK) {
+  return (size_t)waves_per_block * (size_t)(stack_depth * 64 + point_words + 32) * 4;
 }
 inline unsigned long long scratch_floats_per_wave(int max_depth) {
   int levels = max_depth > 1 ? max_depth - 1 : 0;  // level 1 (primary) is never queued

@@ -597,12 +597,15 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
   }
 }
 
-template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT>
-__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
+// WPB waves per block: 4, or 8 for scenes whose LDS copy only fits when two (not four) blocks
+// share a CU's 160 KB -- the waves never synchronise after the staging barrier, so the block
+// size is only a unit of LDS sharing.
+template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT, int WPB = WAVES_PER_BLOCK>
+__global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
   extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  const unsigned long long gwave = (unsigned long long)blockIdx.x * WAVES_PER_BLOCK + wib;
+  const unsigned long long gwave = (unsigned long long)blockIdx.x * WPB + wib;
   // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | tag table | level counters]
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
@@ -615,18 +618,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // the block's one and only barrier: stage the scene (a few KB) once per persistent block
     float4 *dst = reinterpret_cast<float4 *>(lds);
     const int n_f4 = (P.n_node_recs + P.n_prim_recs) * 4;
-    for (int i = threadIdx.x; i < n_f4; i += 256) {
+    for (int i = threadIdx.x; i < n_f4; i += 64 * WPB) {
       const int rec = i >> 2, part = i & 3;
       const float4 v = rec < P.n_node_recs ? P.nodes[(size_t)rec * NODE_F4 + part]
                                            : P.prims[(size_t)(rec - P.n_node_recs) * PRIM_F4 + part];
       dst[(size_t)rec * LDS_REC_F4 + part] = v;
     }
-    for (int i = threadIdx.x; i < P.n_materials * 12; i += 256) lds[rec_words + i] = __float_as_uint(P.materials[i]);
+    for (int i = threadIdx.x; i < P.n_materials * 12; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
     __syncthreads();
   }
-  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + POINT_WORDS + 32);
-  unsigned *pts = stack + P.stack_depth * 64;  // shaded points of the step (shadow_lights)
-  unsigned *cnt = pts + POINT_WORDS;           // cnt[L], L = 2..max_depth : rays queued at level L
+  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
+  unsigned *pts = stack + P.stack_depth * 64;  // shaded points of the step (shadow_lights; MLIGHT builds)
+  unsigned *cnt = pts + P.point_words;           // cnt[L], L = 2..max_depth : rays queued at level L
 
   float *Q = P.scratch + gwave * P.scratch_stride;
   long long *acc = P.acc;  // [n_local_pixels][3] fixed point
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
   __shared__ unsigned hist[PROBE_CLASSES];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + POINT_WORDS + 32);
+  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
   if (threadIdx.x < PROBE_CLASSES) hist[threadIdx.x] = 0;
   __syncthreads();
   const int span = P.probe_span;  // packets per block (multiple of 64)
@@ -1196,7 +1199,18 @@ __global__ void resolve_kernel(const RenderParams P) {
 
 template <bool PRUNE, bool COUNT>
 static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
-  if (cfg.mlight && PRUNE && !COUNT) {
+  if (cfg.block == 512) {  // LDS scene, pruned, uncounted (chosen by the host only then)
+    // more than 64 KB of dynamic LDS has to be asked for (per device; a cheap host-side call)
+    if (cfg.mlight) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, true, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+      hipLaunchKernelGGL((render_kernel<true, false, true, true, 8>), dim3(cfg.grid), dim3(512), cfg.lds_bytes, s, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, false, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+      hipLaunchKernelGGL((render_kernel<true, false, true, false, 8>), dim3(cfg.grid), dim3(512), cfg.lds_bytes, s, p);
+    }
+  } else if (cfg.mlight && PRUNE && !COUNT) {
     if (cfg.lds_scene)
       hipLaunchKernelGGL((render_kernel<true, false, true, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
     else
@@ -1234,10 +1248,13 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, size_t lds_bytes) {
+static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes) {
   int n = 0;
   hipError_t e;
-  if (mlight && prune && !count) {
+  if (block == 512) {
+    if (mlight) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true, 8>, 512, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, 8>, 512, lds_bytes);
+  } else if (mlight && prune && !count) {
     if (lds_scene) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true>, 256, lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, true>, 256, lds_bytes);
   } else if (lds_scene && !count) {
