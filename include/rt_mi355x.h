@@ -125,9 +125,13 @@ typedef struct rt_camera {
  * to v_fma_f32); hit decisions on ill-conditioned self-intersections may differ,
  * the mismatch rate is reported by the parity tests. */
 #define RT_FLAG_FMA            0x1u
-/* Trace reflection rays whose weight is exactly (0,0,0) too, as the reference
- * does (src/RayTracer.hs:129-131 always recurses).  Off by default: such a
- * subtree can only change the result if it produces inf/NaN. */
+/* Trace every ray the reference traces: also reflection rays whose weight is
+ * exactly (0,0,0) (src/RayTracer.hs:129-131 always recurses) and inShadow rays
+ * towards lights whose diffuse AND specular factors are both exactly zero for
+ * the point (max 0 (l.n) = 0 and max 0 (n.h) = 0, src/RayTracer.hs:101-105: the
+ * light adds 0 + 0 whether occluded or not).  Off by default: such rays can only
+ * change the result if they produce inf/NaN; they are then neither traced nor
+ * counted in rt_stats. */
 #define RT_FLAG_TRACE_ZERO_WEIGHT 0x2u
 /* Visit every node whose ancestors pass hitsBox, like hitBVH
  * (src/RayTracer.hs:404-412): no front-to-back order, no t-range pruning. */

@@ -27,7 +27,7 @@
 #include <omp.h>
 #endif
 
-#define RTO_FLAG_CULL_ZERO_WEIGHT 0x1u /* mirror of the GPU's default ray culling */
+#define RTO_FLAG_CULL_ZERO_WEIGHT 0x1u /* mirror of the GPU's default ray culling: zero-weight bounce rays, shadow rays of lights with zero factors */
 
 typedef struct rto_stats {
   uint64_t rays_primary, rays_shadow, rays_reflection, rays_refraction;
@@ -210,6 +210,14 @@ static color direct_color(octx *o, int li, float ra, float rb, const rt_material
                                       v3(l_b.x * rb, l_b.y * rb, l_b.z * rb)));
   vec3 l = subt(l_pt, pt);
   vec3 l_dir = normalize(l);
+  float p = mt->phong;
+  /* GPU default policy (flag only): a light whose diffuse AND specular factors are both exactly
+   * zero -- max 0 (l.n) = 0 and max 0 (n.h) = 0 with a positive Phong exponent -- adds (0 + 0) to
+   * the colour whether or not it is occluded, so its inShadow ray is neither traced nor counted.
+   * The decision uses only the reference's own single-rounded dot products. */
+  if ((o->flags & RTO_FLAG_CULL_ZERO_WEIGHT) && dot(l_dir, n) <= 0 &&
+      dot(n, normalize(add(v, l_dir))) <= 0 && p > 0)
+    return direct_color(o, li + 1, ra, rb, mt, pt, n, v);
   int shadowed = in_shadow(o, pt, l_dir, magnitude(l));
   color rest = direct_color(o, li + 1, ra, rb, mt, pt, n, v);
   if (shadowed) return rest;
@@ -217,7 +225,6 @@ static color direct_color(octx *o, int li, float ra, float rb, const rt_material
   float s = hs_max(0.0f, dot(l_dir, n));
   color diffuse_c = cscale(cmul(ldc(mt->diffuse), l_c), s);
   vec3 h = normalize(add(v, l_dir));
-  float p = mt->phong;
   float pw = powf(hs_max(0.0f, dot(n, h)), p);
   color spec_c = cscale(cmul(l_c, ldc(mt->specular)), pw);
   color c = cadd(diffuse_c, spec_c);

@@ -37,7 +37,7 @@ constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS s
 
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
 constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
-constexpr int POINT_WORDS = 6 * 64;  // LDS per wave: x, y, z, s0, s1, occlusion mask of the step's <= 64 shaded points
+constexpr int POINT_WORDS = 8 * 64;  // LDS per wave (multi-light builds): x, y, z, s0, s1, occlusion mask of the step's points, hand-out table, per-light masks
 constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)

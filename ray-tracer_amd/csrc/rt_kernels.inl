@@ -344,38 +344,57 @@ DEVI void light_ray(const RenderParams &P, int li, V3 pt, float s0, float s1, V3
   max_d = magnitude(l);
 }
 
+// Default ray policy (not with RT_FLAG_TRACE_ZERO_WEIGHT): a light whose diffuse AND specular
+// factors are both exactly zero for this point -- max 0 (l.n) = 0 and max 0 (n.h) = 0 with a
+// positive Phong exponent (getDirectColor :101-105) -- adds (0 + 0) to the colour whether or not
+// it is occluded, so its inShadow ray is neither traced nor counted.  The decision uses only the
+// reference's own single-rounded dot products (the oracle takes it the same way).
+DEVI bool light_matters(V3 l_dir, V3 n, V3 v, float phong) {
+  return !(dot(l_dir, n) <= 0 && dot(n, normalize(add(v, l_dir))) <= 0 && phong > 0);
+}
+
 // inShadow (:231-235) for lights lo .. hi-1 (hi - lo <= 32) of the wave's shaded points, one
-// point per `hit` lane: bit (li - lo) of the result is set when light li is occluded.
-// The (point, light) pairs form ONE pool of shadow rays for the wave, light-major so that rays
-// in flight together mostly aim at the same light.  The points are parked in LDS and every
-// lane -- also those whose own ray missed -- takes the next ray of the pool whenever its
-// current one is decided ("dynamic fetch"), instead of the wave walking the light list in
+// point per `hit` lane.  `need` (in): bit (li - lo) set = this lane's point needs the shadow
+// ray of light li.  Returns the same layout with a bit set where the light is occluded.
+// The needed (point, light) pairs form ONE pool of shadow rays for the wave, light by light
+// so that rays in flight together mostly aim at the same light.  The points are parked in LDS
+// and every lane -- also those whose own ray missed -- takes the next ray of the pool whenever
+// its current one is decided ("dynamic fetch"), instead of the wave walking the light list in
 // lockstep with only the `hit` lanes and waiting for the slowest ray of every light.  An
 // occluded ray ORs its bit into the owner's mask in LDS.  The answers are per-ray facts: who
 // computes them, and in which order, cannot change them (the light ray is recomputed from
 // the same operands by the same operations).
 // Lanes are re-armed only when P.rearm_min of them are idle (or nothing else is running): the
 // set-up code is issued for the whole wave whoever needs it.
+// LDS, 64 words each: x, y, z, s0, s1, occlusion mask (indexed by the owner's lane), hand-out
+// table, per-light 64-bit masks of the points that need the light.
 template <bool PRUNE, bool COUNT, bool LDS>
 DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *pts, int lane,
-                            unsigned long long lt_mask, bool hit, V3 pt, float s0, float s1, int hi, int lo,
-                            Counters &cn) {
-  const unsigned long long hm = __ballot(hit);
-  const int nhit = __popcll(hm);
-  if (!P.has_root || nhit == 0) return 0;
-  const int slot = __popcll(hm & lt_mask);
+                            unsigned long long lt_mask, bool hit, V3 pt, float s0, float s1, unsigned need,
+                            int hi, int lo, Counters &cn) {
+  if (!P.has_root) return 0;
+  unsigned *occl = pts + 5 * 64, *handout = pts + 6 * 64, *lmask = pts + 7 * 64;
+  int remaining = 0;  // rays of the pool not handed out yet (wave-uniform)
+  for (int b = 0; b < hi - lo; ++b) {
+    const unsigned long long m = __ballot(hit && ((need >> b) & 1u));
+    remaining += __popcll(m);
+    if (lane == 0) {
+      lmask[2 * b] = (unsigned)m;
+      lmask[2 * b + 1] = (unsigned)(m >> 32);
+    }
+  }
+  if (remaining == 0) return 0;
   if (hit) {
-    pts[0 * 64 + slot] = __float_as_uint(pt.x);
-    pts[1 * 64 + slot] = __float_as_uint(pt.y);
-    pts[2 * 64 + slot] = __float_as_uint(pt.z);
-    pts[3 * 64 + slot] = __float_as_uint(s0);
-    pts[4 * 64 + slot] = __float_as_uint(s1);
-    pts[5 * 64 + slot] = 0u;
+    pts[0 * 64 + lane] = __float_as_uint(pt.x);
+    pts[1 * 64 + lane] = __float_as_uint(pt.y);
+    pts[2 * 64 + lane] = __float_as_uint(pt.z);
+    pts[3 * 64 + lane] = __float_as_uint(s0);
+    pts[4 * 64 + lane] = __float_as_uint(s1);
+    occl[lane] = 0u;
   }
   __threadfence_block();  // other lanes of this wave read them
-  const int n_items = nhit * (hi - lo);
-  const float inv_nhit = 1.0f / (float)nhit;
-  int next_item = 0;  // wave-uniform
+  int cl = hi - lo;                // current light (bit index); its unserved points in `rm`
+  unsigned long long rm = 0ull;    // both wave-uniform
   int cur = STOP, sp = 0, owner = 0, bit = 0;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
   float tlimit = 0.0f;
@@ -384,16 +403,25 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   rd.safe = true;
   for (;;) {
     const unsigned long long idle = __ballot(cur == STOP);
-    const int remaining = n_items - next_item;
     if (remaining > 0 && (~idle == 0ull || __popcll(idle) >= P.rearm_min)) {
+      while (rm == 0ull) {  // next light with work (there is one: remaining > 0)
+        --cl;
+        rm = ((unsigned long long)lmask[2 * cl + 1] << 32) | lmask[2 * cl];
+        rm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rm >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)rm);
+      }
+      const int n_idle = __popcll(idle), n_left = __popcll(rm);
+      const int n_take = n_idle < n_left ? n_idle : n_left;
+      // the first n_take points of rm publish their lane; the first n_take idle lanes take them
+      const bool served = ((rm >> lane) & 1ull) && __popcll(rm & lt_mask) < n_take;
+      if (served) handout[__popcll(rm & lt_mask)] = (unsigned)lane;
+      rm &= ~__ballot(served);
+      remaining -= n_take;
+      __threadfence_block();
       const int rank = __popcll(idle & lt_mask);
-      if (cur == STOP && rank < remaining) {
-        const int k = next_item + rank;
-        int lg = (int)((float)k * inv_nhit);  // k / nhit, k < 2048: off by one at most
-        if (lg * nhit > k) --lg;
-        if ((lg + 1) * nhit <= k) ++lg;
-        owner = k - lg * nhit;
-        bit = hi - 1 - lg - lo;
+      if (cur == STOP && rank < n_take) {
+        owner = (int)handout[rank];
+        bit = cl;
         o = mk(__uint_as_float(pts[0 * 64 + owner]), __uint_as_float(pts[1 * 64 + owner]),
                __uint_as_float(pts[2 * 64 + owner]));
         light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
@@ -402,8 +430,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
         sp = 0;
         cur = 0;
       }
-      const int armed = __popcll(idle);
-      next_item += armed < remaining ? armed : remaining;
+      __threadfence_block();  // the hand-out table is rewritten by the next re-arm
     }
     const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
     if ((at_node | at_leaf) == 0) break;
@@ -418,11 +445,11 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       float bt = tlimit;
       int bp = -1;
       leaf_step<true, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, bt, bp, cur, sp, cn);
-      if (bp >= 0) atomicOr(&pts[5 * 64 + owner], 1u << bit);
+      if (bp >= 0) atomicOr(&occl[owner], 1u << bit);
     }
   }
   __threadfence_block();
-  return hit ? pts[5 * 64 + slot] : 0u;
+  return hit ? occl[lane] : 0u;
 }
 
 // reflect / refract / orthonormal (RayTracer.hs:162-179, 453-459)
@@ -795,17 +822,35 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
     // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
     // exactly that order.
     if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
+    const bool cull_unlit = !P.trace_zero_weight;
     if (MLIGHT) {
-      // several lights (the host picks this build for them): all shadow rays of the point first (lanes run ahead of each other
-      // through the light list), then the lit terms in the reference's order
+      // several lights (the host picks this build for them): which lights matter to the point,
+      // then all their shadow rays as one pool, then the lit terms in the reference's order
       for (int hi = P.n_lights; hi > 0; hi -= 32) {
         const int lo = hi > 32 ? hi - 32 : 0;
+        unsigned need = 0;
+        if (hit) {
+          need = (hi - lo == 32) ? ~0u : ((1u << (hi - lo)) - 1u);
+          if (cull_unlit)
+            for (int li = hi - 1; li >= lo; --li) {
+              V3 l_dir;
+              float max_d;
+              light_ray(P, li, pt, s0, s1, l_dir, max_d);
+              if (!light_matters(l_dir, n, v, M[6])) need &= ~(1u << (li - lo));
+            }
+        }
         PH_MARK(2);
-        const unsigned occluded = shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, hi, lo, cn);
+        const unsigned occluded =
+            shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, need, hi, lo, cn);
         PH_MARK(3);
-        n_shadow += __popcll(__ballot(hit)) * (hi - lo);
+        {
+          unsigned long long cnt_rays = (unsigned long long)__popc(need);  // wave sum below
+          for (int dlt = 32; dlt >= 1; dlt >>= 1) cnt_rays += __shfl_xor(cnt_rays, dlt);
+          n_shadow += cnt_rays;
+        }
+        const unsigned lit = need & ~occluded;
         for (int li = hi - 1; li >= lo; --li) {
-          if (hit && !((occluded >> (li - lo)) & 1u)) {
+          if ((lit >> (li - lo)) & 1u) {
             V3 l_dir;
             float max_d;
             light_ray(P, li, pt, s0, s1, l_dir, max_d);
@@ -824,13 +869,17 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
       V3 l_dir;
       float max_d;
       light_ray(P, li, pt, s0, s1, l_dir, max_d);
+      // (the half vector is only formed here for the few lanes whose light is behind the surface;
+      //  nothing but `need` stays live across the traversal)
+      bool need = hit;
+      if (cull_unlit && hit && dot(l_dir, n) <= 0) need = light_matters(l_dir, n, v, M[6]);
       float st;
       int sprim;
       PH_MARK(2);
-      traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, hit, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, need, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
       PH_MARK(3);
-      n_shadow += __popcll(__ballot(hit));
-      if (hit && sprim < 0) {
+      n_shadow += __popcll(__ballot(need));
+      if (need && sprim < 0) {
         V3 l_c = ld3(P.lights + (size_t)li * 12 + 9);
         float s = hs_max(0.0f, dot(l_dir, n));
         V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
