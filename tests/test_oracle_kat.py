@@ -268,3 +268,23 @@ def test_shadowed_point_gets_ambient_only(rt, oracle):
     oracle.lib().rto_raytrace(C.byref(sc.view), C.byref(cam), 1, f32(0.5), f32(0.5),
                               v3((-1, 1, 2)), v3(d), 0, rgb)
     assert np.allclose(list(rgb), [0.1, 0.1, 0.1], rtol=1e-6)
+
+
+def test_default_ray_policy_never_changes_a_finite_pixel(rt, oracle):
+    """The GPU's default policy, mirrored by the oracle's FLAG_CULL_ZERO_WEIGHT: reflection rays
+    of weight (0,0,0) and inShadow rays of lights whose diffuse and specular factors are both
+    zero (max 0 (l.n) = 0 and max 0 (n.h) = 0, RayTracer.hs:101-105) are not traced.  They can
+    only contribute 0, so every finite pixel and every primary hit id is bit-identical to the
+    reference's full accounting; only the ray counts drop."""
+    from conftest import make_world
+    for name, rpp in (("bench1", 4), ("bench2", 1), ("mesh:3000", 1), ("bench5", 4)):
+        w = make_world(rt, name, 72, 40, rpp)
+        grids = rt.generate_grids(31, w.width + 10, w.camera.aa)
+        a_rgb, a_ids, a_st = oracle.render(w, grids, 0)
+        b_rgb, b_ids, b_st = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT)
+        assert np.array_equal(a_ids, b_ids)
+        fin = np.isfinite(a_rgb) & np.isfinite(b_rgb)
+        assert np.array_equal(a_rgb[fin], b_rgb[fin])
+        assert b_st.rays_primary == a_st.rays_primary
+        assert b_st.rays_shadow <= a_st.rays_shadow and b_st.rays_reflection <= a_st.rays_reflection
+        assert b_st.rays_total < a_st.rays_total
