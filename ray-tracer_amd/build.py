@@ -49,7 +49,7 @@ def build_device(force=False, defines=(), tag=""):
     obj = os.path.join(HERE, "build" + tag)
     os.makedirs(obj, exist_ok=True)
     out = os.path.join(LIB, f"librt_mi355x{tag}.so")
-    common = [os.path.join(CSRC, "rt_device.h"), os.path.join(INC, "rt_mi355x.h")]
+    common = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_fastdiv.h"), os.path.join(INC, "rt_mi355x.h")]
     kern = os.path.join(CSRC, "rt_kernels.inl")
     units = [
         ("rt_kernels_strict", ["-ffp-contract=off"], [kern]),

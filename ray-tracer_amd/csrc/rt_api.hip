@@ -342,6 +342,11 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.chunks_per_packet = (c->spp + 63) / 64;
   p.groups_per_tile = (c->tiling.tile_w * c->tiling.tile_h + p.px_per_packet - 1) / p.px_per_packet;
   p.n_packets = c->tiling.n_local_tiles * p.groups_per_tile;
+  p.fd_groups_per_tile = make_fastdiv((unsigned)p.groups_per_tile);
+  p.fd_tiles_x = make_fastdiv((unsigned)p.tiles_x);
+  p.fd_spp = make_fastdiv((unsigned)p.spp);
+  p.fd_tile_w = make_fastdiv((unsigned)p.tile_w);
+  p.fd_n_grids = make_fastdiv((unsigned)p.n_grids);
   p.tile_counter = c->d_tile_counter;
   p.stats = c->d_stats;
   p.stack_depth = c->stack_depth;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "rt_fastdiv.h"
 #include <stdint.h>
 
 #include "rt_mi355x.h"
@@ -80,6 +81,7 @@ struct RenderParams {
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
+  FastDiv fd_groups_per_tile, fd_tiles_x, fd_spp, fd_tile_w, fd_n_grids;  // the hot loop's divisors
   int point_words;                       // LDS words per wave for the step's shaded points (POINT_WORDS, or 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
 };

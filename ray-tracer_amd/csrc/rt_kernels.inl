@@ -490,6 +490,13 @@ DEVI void get_ray(const RenderParams &P, float i, float j, float r1, float r2, V
   dirn = normalize(fdir);
 }
 
+// n / d with the host's magic numbers (rt_device.h make_fastdiv); exact for all n < 2^32
+DEVI unsigned fdiv(unsigned n, const FastDiv &f) {
+  const unsigned q = __umulhi(n, f.magic);
+  const unsigned t = ((n - q) >> 1) + q;
+  return f.d == 1u ? n : (t >> f.shift);
+}
+
 DEVI int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 constexpr unsigned SLOT_REFRACTION = 0x80000000u;
@@ -705,10 +712,11 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
     int px = 0, py = 0, smp = 0;
     if (level == 1) {
       const int packet_id = cur_packet >> 7, code = cur_packet & 127;
-      const int ltile = packet_id / P.groups_per_tile, grp = packet_id - ltile * P.groups_per_tile;
+      const int ltile = (int)fdiv((unsigned)packet_id, P.fd_groups_per_tile), grp = packet_id - ltile * P.groups_per_tile;
       const int gtile = P.rank + ltile * P.nranks;
-      const int tx0 = (gtile % P.tiles_x) * P.tile_w;
-      const int ty0 = (gtile / P.tiles_x) * P.tile_h;
+      const int tyi = (int)fdiv((unsigned)gtile, P.fd_tiles_x);
+      const int tx0 = (gtile - tyi * P.tiles_x) * P.tile_w;
+      const int ty0 = tyi * P.tile_h;
       int pit;
       bool in_packet;
       if (P.spp <= 64 && code != ENTRY_WHOLE) {  // single-pixel entry
@@ -716,7 +724,7 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
         pit = grp * P.px_per_packet + code;
         in_packet = lane < P.spp;
       } else if (P.spp <= 64) {
-        int sub = lane / P.spp;
+        int sub = (int)fdiv((unsigned)lane, P.fd_spp);
         smp = lane - sub * P.spp;
         pit = grp * P.px_per_packet + sub;
         in_packet = sub < P.px_per_packet;
@@ -725,8 +733,9 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
         pit = grp;
         in_packet = smp < P.spp;
       }
-      px = tx0 + pit % P.tile_w;
-      py = ty0 + pit / P.tile_w;
+      const int prow = (int)fdiv((unsigned)pit, P.fd_tile_w);
+      px = tx0 + (pit - prow * P.tile_w);
+      py = ty0 + prow;
       active = in_packet && (pit < tile_px) && (px < P.W) && (py < P.H);
       pix = (unsigned)(ltile * tile_px + pit);
       W = mk(1.0f, 1.0f, 1.0f);
@@ -735,7 +744,8 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
       if (active) {
         // render (RayTracer.hs:18-23): list position k uses grid k mod n_grids
         const unsigned kpix = (unsigned)py * (unsigned)P.W + (unsigned)px;  // < 2^32 (checked on the host)
-        const float *F = P.f6 + ((size_t)(kpix % (unsigned)P.n_grids) * (size_t)P.spp + smp) * 6;
+        const unsigned grid = kpix - fdiv(kpix, P.fd_n_grids) * (unsigned)P.n_grids;  // kpix mod n_grids
+        const float *F = P.f6 + ((size_t)grid * (size_t)P.spp + smp) * 6;
         float fi = (float)px, fj = (float)(P.H - 1 - py);
         get_ray(P, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
         s0 = F[4];

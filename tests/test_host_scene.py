@@ -210,3 +210,15 @@ def test_oracle_no_bvh_equals_sah_bvh(rt, oracle):
             assert a_st.rays_total == b_st.rays_total
             fin = np.isfinite(a_rgb) & np.isfinite(b_rgb)
             assert np.array_equal(a_rgb[fin], b_rgb[fin])
+
+
+def test_fastdiv_constants_are_exact(tmp_path):
+    """ray-tracer_amd/csrc/rt_fastdiv.h (the hot loop's divisions by launch constants: pixels per
+    tile row, samples per pixel, grids): tools/check_fastdiv.cpp compares 22 M quotients with `/`."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "check_fastdiv")
+    subprocess.run(["g++", "-O2", "-I", os.path.join(root, "ray-tracer_amd", "csrc"),
+                    os.path.join(root, "tools", "check_fastdiv.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "fastdiv ok" in p.stdout, p.stdout[-500:]
