@@ -976,13 +976,6 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
       if (hit) {
         V3 spec = ld3(M + 3);
         float phong = M[6], reflx = M[7], nt = M[8];
-        V3 refl0 = reflect(d, n);
-        V3 ou, ov;
-        orthonormal(refl0, ou, ov);
-        float a = 1 / phong;
-        float ju = -(a / 2) + s0 * a;
-        float jv = -(a / 2) + s1 * a;
-        refl_v = add(refl0, add(multiply(ou, ju), multiply(ov, jv)));
         V3 f_refl = cscale(spec, reflx);
         e_refl = true;
         if (nt != 0) {
@@ -1013,6 +1006,17 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
         if (!P.trace_zero_weight) {
           if (w_refl.x == 0 && w_refl.y == 0 && w_refl.z == 0) e_refl = false;
           if (e_refr && w_refr.x == 0 && w_refr.y == 0 && w_refr.z == 0) e_refr = false;
+        }
+        // the jittered reflection direction (:113-121) only where a reflection ray is emitted:
+        // waves whose hits are all on non-reflective materials skip it altogether
+        if (e_refl) {
+          V3 refl0 = reflect(d, n);
+          V3 ou, ov;
+          orthonormal(refl0, ou, ov);
+          float a = 1 / phong;
+          float ju = -(a / 2) + s0 * a;
+          float jv = -(a / 2) + s1 * a;
+          refl_v = add(refl0, add(multiply(ou, ju), multiply(ov, jv)));
         }
       }
       unsigned long long m1 = __ballot(e_refl), m2 = __ballot(e_refr);
