@@ -20,6 +20,7 @@ struct rt_ctx {
   int device = 0;
   int n_cus = 0;
   hipStream_t stream = nullptr;
+  hipStream_t last_launch_stream = nullptr;  // where the newest frame was enqueued (caller's or ours)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
   bool timed = false;
   std::string err;
@@ -27,6 +28,7 @@ struct rt_ctx {
   // scene
   float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
+  size_t cap_nodes = 0, cap_prims = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
@@ -89,15 +91,30 @@ int fail(rt_ctx *c, int code, const char *fmt, ...) {
                   __LINE__);                                                                 \
   } while (0)
 
+// Host -> device copy of one of the context's input tables.  The allocation is kept while it
+// is large enough (an animation uploads a same-sized scene every frame), and the copy is
+// ordered on the CONTEXT's stream and waited for there: it cannot overtake the context's frame
+// in flight, which still reads the old table, and it does not stall the other contexts of
+// the GPU the way hipFree / a null-stream copy (device-wide synchronisation) would.
 template <class T>
-int upload(rt_ctx *c, T **dst, const void *src, size_t bytes) {
-  if (*dst) {
-    (void)hipFree(*dst);
-    *dst = nullptr;
-  }
+int upload(rt_ctx *c, T **dst, size_t *cap, const void *src, size_t bytes) {
   if (bytes == 0) bytes = 16;
-  HIP_TRY(c, hipMalloc((void **)dst, bytes));
-  if (src) HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  if (!*dst || *cap < bytes) {
+    if (*dst) {
+      (void)hipFree(*dst);
+      *dst = nullptr;
+      *cap = 0;
+    }
+    HIP_TRY(c, hipMalloc((void **)dst, bytes));
+    *cap = bytes;
+  }
+  if (src) {
+    // a frame enqueued on a caller's stream is not ordered before c->stream: wait for it first
+    if (c->last_launch_stream && c->last_launch_stream != c->stream)
+      HIP_TRY(c, hipStreamSynchronize(c->last_launch_stream));
+    HIP_TRY(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   return RT_OK;
 }
 
@@ -543,10 +560,10 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if (rp.max_depth > 64)
     return fail(c, RT_ERR_LIMIT, "BVH depth %d exceeds the traversal stack limit of 64", rp.max_depth);
   int rc;
-  if ((rc = upload(c, &c->d_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
-  if ((rc = upload(c, &c->d_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
-  if ((rc = upload(c, &c->d_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
-  if ((rc = upload(c, &c->d_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
+  if ((rc = upload(c, &c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
+  if ((rc = upload(c, &c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
+  if ((rc = upload(c, &c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
+  if ((rc = upload(c, &c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;
   c->n_materials = sc->n_materials;
   c->n_node_recs = (int)(rp.nodes.size() / 16);
@@ -585,7 +602,7 @@ int rt_set_samples(rt_ctx *c, const float *f6, int32_t n_grids, int32_t spp) {
   if (!c || !f6) return RT_ERR_INVALID;
   if (n_grids < 1 || spp < 1 || spp > 1024) return fail(c, RT_ERR_INVALID, "bad sample table shape");
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = upload(c, &c->d_f6, f6, (size_t)n_grids * spp * 6 * sizeof(float));
+  int rc = upload(c, &c->d_f6, &c->cap_f6, f6, (size_t)n_grids * spp * 6 * sizeof(float));
   if (rc) return rc;
   c->n_grids = n_grids;
   c->spp = spp;
@@ -614,12 +631,14 @@ int rt_get_tiling(rt_ctx *c, rt_tiling *out) {
 int rt_render_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_ids, void *stream) {
   if (!c || !d_rgb) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->last_launch_stream = s;
   return launch(c, flags, d_rgb, 0, d_ids, s);
 }
 
 int rt_render_tiles_async(rt_ctx *c, uint32_t flags, float *d_tiles, void *stream) {
   if (!c || !d_tiles) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->last_launch_stream = s;
   return launch(c, flags, d_tiles, 1, nullptr, s);
 }
 
