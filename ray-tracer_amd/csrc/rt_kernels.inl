@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(con
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WPB + wib;
-  // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | tag table | level counters]
+  // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | shaded points (multi-light builds) | level counters]
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
