@@ -32,6 +32,7 @@ struct rt_ctx {
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
+  int five_waves_mode = -1; // RT_FIVE_WAVES: 0 never use the 96-VGPR build
   bool have_scene = false;
   // camera / samples
   rt_camera cam{};
@@ -398,9 +399,16 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   }
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
   cfg.lds_bytes += cfg.lds_scene_bytes;
+  // The 96-VGPR build (five waves per SIMD): small single-light LDS scenes, and only when a wave
+  // has many packets to work through -- on a small share of a frame the extra waves only add
+  // start-up and queue-drain steps (1/8 of c2: 0.71 -> 0.79 ms; whole frame, pipelined: 2.42 -> 2.36).
+  cfg.five_waves = cfg.lds_scene && cfg.block == 64 * WAVES_PER_BLOCK && cfg.prune && !cfg.count && !cfg.mlight &&
+                   cfg.lds_bytes <= 32 * 1024 &&  // five 4-wave blocks share a CU's 160 KB
+                   (c->five_waves_mode > 0 ||
+                    (c->five_waves_mode < 0 && (long long)p.n_packets >= 64ll * c->n_cus * 20));
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.block, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.block, cfg.lds_bytes);
+  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes)
+                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + wpb - 1) / wpb;
@@ -500,6 +508,7 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REARM_MIN")) c->rearm_min = std::atoi(e);
+  if (const char *e = std::getenv("RT_FIVE_WAVES")) c->five_waves_mode = std::atoi(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&

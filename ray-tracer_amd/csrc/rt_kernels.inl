@@ -634,11 +634,17 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
 // WPB waves per block: 4, or 8 for scenes whose LDS copy only fits when two (not four) blocks
 // share a CU's 160 KB -- the waves never synchronise after the staging barrier, so the block
 // size is only a unit of LDS sharing.
-template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT, int WPB = WAVES_PER_BLOCK>
-__global__ __launch_bounds__(64 * WPB, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P) {
+// WPS waves per SIMD the registers are budgeted for: 4 (128 VGPRs), or 5 (96 VGPRs, a dozen
+// spilled) for the small-scene single-light build, where the fifth wave buys more than the
+// spills cost once frames are pipelined (c2 2.39 -> 2.34 ms); everywhere else 5 measured slower.
+template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT, int WPB = WAVES_PER_BLOCK, int WPS = RT_WAVES_PER_SIMD>
+__global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParams P) {
   extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
+  // The wave's index in the block is the same in all its lanes.  Saying so moves every pointer
+  // derived from it (stack, queues, counters) into scalar registers: 15 VGPRs fewer, which the
+  // 96-register build needs; the 128-register builds are faster without (more scalar spills).
+  const int wib = WPS > 4 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WPB + wib;
   // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | shaded points (multi-light builds) | level counters]
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
@@ -1279,7 +1285,9 @@ static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s)
     else
       hipLaunchKernelGGL((render_kernel<true, false, false, true>), dim3(cfg.grid), dim3(cfg.block),
                          cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
-  } else if (cfg.lds_scene && !COUNT)
+  } else if (cfg.five_waves)
+    hipLaunchKernelGGL((render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
+  else if (cfg.lds_scene && !COUNT)
     hipLaunchKernelGGL((render_kernel<PRUNE, false, true, false>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
   else
     hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false, false>), dim3(cfg.grid), dim3(cfg.block),
@@ -1311,12 +1319,14 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes) {
+static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
   int n = 0;
   hipError_t e;
   if (block == 512) {
     if (mlight) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true, 8>, 512, lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, 8>, 512, lds_bytes);
+  } else if (five_waves) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>, 256, lds_bytes);
   } else if (mlight && prune && !count) {
     if (lds_scene) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true>, 256, lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, true>, 256, lds_bytes);

@@ -9,7 +9,7 @@ namespace rtdev {
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   fma::launch(p, cfg, s);
 }
-int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes) {
-  return fma::occupancy(prune, count, lds_scene, mlight, block, lds_bytes);
+int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
+  return fma::occupancy(prune, count, lds_scene, mlight, five_waves, block, lds_bytes);
 }
 }  // namespace rtdev

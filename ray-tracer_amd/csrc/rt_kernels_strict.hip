@@ -8,7 +8,7 @@ namespace rtdev {
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   strict::launch(p, cfg, s);
 }
-int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, int block, size_t lds_bytes) {
-  return strict::occupancy(prune, count, lds_scene, mlight, block, lds_bytes);
+int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
+  return strict::occupancy(prune, count, lds_scene, mlight, five_waves, block, lds_bytes);
 }
 }  // namespace rtdev
