@@ -676,7 +676,9 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   const int tile_px = P.tile_w * P.tile_h;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  unsigned long long n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
+  // per-wave ray counters: 32 bits are plenty for one wave's share of a frame (and half the
+  // scalar registers); they are widened when added to the frame's totals
+  unsigned n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
   Counters cn = {0, 0, 0};
   const unsigned long long wave_t0 = wall_clock64();
   unsigned long long t_dry = wave_t0;
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
             shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, need, hi, lo, cn);
         PH_MARK(3);
         {
-          unsigned long long cnt_rays = (unsigned long long)__popc(need);  // wave sum below
+          unsigned cnt_rays = (unsigned)__popc(need);  // wave sum below
           for (int dlt = 32; dlt >= 1; dlt >>= 1) cnt_rays += __shfl_xor(cnt_rays, dlt);
           n_shadow += cnt_rays;
         }
@@ -1069,18 +1071,18 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
 #endif
   if (lane == 0) {
     unsigned long long life = wall_clock64() - wave_t0;  // 100 MHz ticks (diagnostics)
-    atomicAdd(&P.stats[0], n_primary);
-    atomicAdd(&P.stats[1], n_shadow);
-    atomicAdd(&P.stats[2], n_refl);
-    atomicAdd(&P.stats[3], n_refr);
-    atomicAdd(&P.stats[7], n_phits);
-    atomicAdd(&P.stats[8], n_hits);
+    atomicAdd(&P.stats[0], (unsigned long long)n_primary);
+    atomicAdd(&P.stats[1], (unsigned long long)n_shadow);
+    atomicAdd(&P.stats[2], (unsigned long long)n_refl);
+    atomicAdd(&P.stats[3], (unsigned long long)n_refr);
+    atomicAdd(&P.stats[7], (unsigned long long)n_phits);
+    atomicAdd(&P.stats[8], (unsigned long long)n_hits);
     atomicAdd(&P.stats[9], life);
     atomicMax(&P.stats[10], life);
     atomicAdd(&P.stats[11], 1ull);
     // per-wave diagnostics (rt_wave_diag): lifetime ticks, rays processed
     P.stats[16 + gwave * 4] = life;
-    P.stats[17 + gwave * 4] = n_primary + n_shadow + n_refl + n_refr;
+    P.stats[17 + gwave * 4] = (unsigned long long)n_primary + n_shadow + n_refl + n_refr;
     P.stats[18 + gwave * 4] = ((unsigned long long)n_steps << 40) | (wave_t0 & 0xFFFFFFFFFFull);
     P.stats[19 + gwave * 4] = t_dry - wave_t0;  // when the packet supply ran dry for this wave
 #ifdef RT_PROFILE_PHASES
