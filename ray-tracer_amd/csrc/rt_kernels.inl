@@ -680,8 +680,13 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   // scalar registers); they are widened when added to the frame's totals
   unsigned n_primary = 0, n_shadow = 0, n_refl = 0, n_refr = 0, n_phits = 0, n_hits = 0;
   Counters cn = {0, 0, 0};
-  const unsigned long long wave_t0 = wall_clock64();
-  unsigned long long t_dry = wave_t0;
+  // diagnostics (rt_wave_diag): the wave's start time goes straight to memory, not into
+  // registers that would stay live for the whole frame
+  if (lane == 0) {
+    const unsigned long long t0 = wall_clock64();
+    P.stats[16 + gwave * 4] = t0;
+    P.stats[19 + gwave * 4] = t0;
+  }
   unsigned n_steps = 0;
   PH_DECL;
 
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       if (++cur_chunk >= P.chunks_per_packet) {
         cur_packet = fetch_packet(P, lane, psrc);
         cur_chunk = 0;
-        if (cur_packet < 0) t_dry = wall_clock64();
+        if (cur_packet < 0 && lane == 0) P.stats[19 + gwave * 4] = wall_clock64();  // supply ran dry
       }
       PH_MARK(9);
     } else {
@@ -1070,6 +1075,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   }
 #endif
   if (lane == 0) {
+    const unsigned long long wave_t0 = P.stats[16 + gwave * 4];
+    const unsigned long long t_dry = P.stats[19 + gwave * 4];
     unsigned long long life = wall_clock64() - wave_t0;  // 100 MHz ticks (diagnostics)
     atomicAdd(&P.stats[0], (unsigned long long)n_primary);
     atomicAdd(&P.stats[1], (unsigned long long)n_shadow);
