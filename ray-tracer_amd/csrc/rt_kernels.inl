@@ -644,7 +644,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   // The wave's index in the block is the same in all its lanes.  Saying so moves every pointer
   // derived from it (stack, queues, counters) into scalar registers: 15 VGPRs fewer, which the
   // 96-register build needs; the 128-register builds are faster without (more scalar spills).
-  const int wib = WPS > 4 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+  const int wib = (WPS > 4 || MLIGHT) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const unsigned long long gwave = (unsigned long long)blockIdx.x * WPB + wib;
   // LDS: [scene copy (LDS builds only)] [per-wave: traversal stack | shaded points (multi-light builds) | level counters]
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
@@ -866,6 +866,14 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         const unsigned occluded =
             shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, need, hi, lo, cn);
         PH_MARK(3);
+        if (need) {
+          // the point and its light-sample coordinates were parked in LDS for the pool: take them
+          // back from there, so that they do not occupy five registers while the pool runs
+          pt = mk(__uint_as_float(pts[0 * 64 + lane]), __uint_as_float(pts[1 * 64 + lane]),
+                  __uint_as_float(pts[2 * 64 + lane]));
+          s0 = __uint_as_float(pts[3 * 64 + lane]);
+          s1 = __uint_as_float(pts[4 * 64 + lane]);
+        }
         {
           unsigned cnt_rays = (unsigned)__popc(need);  // wave sum below
           for (int dlt = 32; dlt >= 1; dlt >>= 1) cnt_rays += __shfl_xor(cnt_rays, dlt);
