@@ -42,7 +42,7 @@ def build_host(force=False):
     return out
 
 
-def build_device(force=False, defines=(), tag=""):
+def build_device(force=False, defines=(), tag="", cflags=()):
     """tag != "" builds an experiment variant lib/librt_mi355x<tag>.so with extra -D flags
     (select it at run time with RT_MI355X_LIB=<path>)."""
     os.makedirs(LIB, exist_ok=True)
@@ -57,7 +57,7 @@ def build_device(force=False, defines=(), tag=""):
         ("rt_api", ["-ffp-contract=off"], []),
     ]
     base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
-    base += ["-D" + d for d in defines]
+    base += ["-D" + d for d in defines] + list(cflags)
     objs = []
     relink = force
     for name, flags, extra in units:
@@ -79,7 +79,8 @@ def build_all(force=False):
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
+    cflags = [a[8:] for a in sys.argv[1:] if a.startswith("--cflag=")]   # experiments: extra hipcc flags
     if tags:
-        build_device(True, defs, tags[0])
+        build_device(True, defs, tags[0], cflags)
     else:
         build_all("--force" in sys.argv)
