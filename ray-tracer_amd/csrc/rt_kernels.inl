@@ -1340,8 +1340,16 @@ static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool f
   int n = 0;
   hipError_t e;
   if (block == 512) {
-    if (mlight) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true, 8>, 512, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, 8>, 512, lds_bytes);
+    // (more than 64 KB of dynamic LDS has to be allowed before it can be asked about or launched)
+    if (mlight) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, true, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true, 8>, 512, lds_bytes);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, false, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, 8>, 512, lds_bytes);
+    }
   } else if (five_waves) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>, 256, lds_bytes);
   } else if (mlight && prune && !count) {
