@@ -344,6 +344,15 @@ DEVI void light_ray(const RenderParams &P, int li, V3 pt, float s0, float s1, V3
   max_d = magnitude(l);
 }
 
+// x ** p of the Phong term (:104).  pow(x, 1) is x for every x (NaN, 0 and inf included), so a
+// wave whose lit lanes all carry exponent 1 (the matte materials of the shipped scenes) skips
+// the ~100-instruction powf expansion altogether; mixed waves select per lane.
+DEVI float phong_pow(float x, float p) {
+  if (__ballot(p != 1.0f) == 0ull) return x;
+  const float w = powf(x, p);
+  return p == 1.0f ? x : w;
+}
+
 // Default ray policy (not with RT_FLAG_TRACE_ZERO_WEIGHT): a light whose diffuse AND specular
 // factors are both exactly zero for this point -- max 0 (l.n) = 0 and max 0 (n.h) = 0 with a
 // positive Phong exponent (getDirectColor :101-105) -- adds (0 + 0) to the colour whether or not
@@ -889,7 +898,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
             float s = hs_max(0.0f, dot(l_dir, n));
             V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
             V3 h = normalize(add(v, l_dir));
-            float pw = powf(hs_max(0.0f, dot(n, h)), M[6]);
+            float pw = phong_pow(hs_max(0.0f, dot(n, h)), M[6]);
             V3 spec_c = cscale(cmul(l_c, ld3(M + 3)), pw);
             clr = add(add(diffuse_c, spec_c), clr);
           }
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         float s = hs_max(0.0f, dot(l_dir, n));
         V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
         V3 h = normalize(add(v, l_dir));
-        float pw = powf(hs_max(0.0f, dot(n, h)), M[6]);
+        float pw = phong_pow(hs_max(0.0f, dot(n, h)), M[6]);
         V3 spec_c = cscale(cmul(l_c, ld3(M + 3)), pw);
         clr = add(add(diffuse_c, spec_c), clr);
       }
