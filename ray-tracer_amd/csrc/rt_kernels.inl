@@ -1150,19 +1150,22 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
   unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
   if (threadIdx.x < PROBE_CLASSES) hist[threadIdx.x] = 0;
   __syncthreads();
-  const int span = P.probe_span;  // packets per block (multiple of 64)
+  const int span = P.probe_span;  // packets per block (multiple of 256)
   const int first = blockIdx.x * span;
   Counters cn = {0, 0, 0};
-  for (int base = first; base < first + span; base += 64) {  // uniform trip count per block
-    const int packet = base + (int)(threadIdx.x >> 2), sub = (int)(threadIdx.x & 3);
+  // probe rays per packet: two (through opposite quadrants of two of its pixels) when the packet
+  // has several pixels, one through the centre when it is a single pixel (64 spp and more)
+  const int two = P.px_per_packet >= 2 ? 1 : 0;
+  for (int base = first; base < first + span; base += 256 >> two) {  // uniform trip count per block
+    const int packet = base + (int)(threadIdx.x >> two), sub = two ? (int)(threadIdx.x & 1) * 3 : 0;
     bool inside = false;
     int px = 0, py = 0;
     const bool valid = packet < P.n_packets && packet < first + span;
     if (valid) decode_packet(P, packet, sub, px, py, inside);
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (inside) {
-      float fi = (float)px + (0.25f + 0.5f * (float)(sub & 1));
-      float fj = (float)(P.H - 1 - py) + (0.25f + 0.5f * (float)(sub >> 1));
+      float fi = (float)px + (two ? 0.25f + 0.5f * (float)(sub & 1) : 0.5f);
+      float fj = (float)(P.H - 1 - py) + (two ? 0.25f + 0.5f * (float)(sub >> 1) : 0.5f);
       get_ray(P, fi, fj, 0.5f, 0.5f, o, d);
     }
     float t;
@@ -1176,8 +1179,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
       bool mirror = (M[3] * refl != 0) || (M[4] * refl != 0) || (M[5] * refl != 0);
       cls = (M[8] != 0) ? 3 : (mirror ? 2 : 1);
     }
-    cls = max(cls, __shfl_xor(cls, 1));
-    cls = max(cls, __shfl_xor(cls, 2));
+    if (two) cls = max(cls, __shfl_xor(cls, 1));
     if (valid && sub == 0) {
       P.pclass[packet] = (unsigned char)cls;
       atomicAdd(&hist[cls], 1u);
