@@ -48,6 +48,7 @@ struct rt_ctx {
   size_t scratch_floats = 0;
   unsigned long long scratch_stride = 0;
   int scratch_waves = 0;
+  bool acc_clean = false;  // every pixel sum of d_acc is zero (left so by resolve_kernel)
   unsigned *d_tile_counter = nullptr;
   unsigned long long *d_stats = nullptr;
   long long *d_acc = nullptr;
@@ -276,6 +277,7 @@ int prepare(rt_ctx *c, uint32_t flags) {
     c->acc_samples = 0;
     HIP_TRY(c, hipMalloc((void **)&c->d_acc, need_samples * 3 * sizeof(long long)));
     c->acc_samples = need_samples;
+    c->acc_clean = false;
   }
   int waves = c->n_cus * 8 * WAVES_PER_BLOCK;  // upper bound on resident waves
   size_t need = std::max<size_t>(64, (size_t)waves * c->scratch_stride);
@@ -439,15 +441,23 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.block_hist = c->d_block_hist;
   p.class_totals = c->d_block_hist + 1024 * 4;
   p.order = c->d_order;
-  HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
-  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
-  HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
-  // pixel accumulators start at zero (the kernel only adds, with atomics)
-  HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h * 3 * sizeof(long long), s));
+  // Ticket counters and statistics are cleared by order_kernel (which precedes render_kernel),
+  // the pixel sums by the previous frame's resolve_kernel after it has read them; explicit
+  // clears only where those have not run: no packets, or sums not known to be zero (new or
+  // resized buffer, a frame that failed half way).
+  if (p.n_packets == 0) {
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
+  }
+  if (!c->acc_clean)
+    HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, c->acc_samples * 3 * sizeof(long long), s));
+  c->acc_clean = false;
   HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
   HIP_TRY(c, hipGetLastError());
+  c->acc_clean = true;  // resolve_kernel is enqueued: it leaves every sum it reads at zero
   HIP_TRY(c, hipEventRecord(c->ev1, s));
   c->timed = true;
   return RT_OK;

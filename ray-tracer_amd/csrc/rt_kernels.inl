@@ -1197,6 +1197,13 @@ __global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
   __shared__ unsigned wcount[4][PROBE_CLASSES];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int nb = gridDim.x;
+  // the frame's ticket counters and statistics start at zero: cleared here, in a kernel that
+  // runs before render_kernel anyway, instead of by three more operations on the stream
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < PACKET_SHARDS * 32; i += 256) P.tile_counter[i] = 0u;
+    if (threadIdx.x < 16) P.stats[threadIdx.x] = 0ull;
+    if (threadIdx.x < 32) P.stats[16 + 4 * 16384 + threadIdx.x] = 0ull;
+  }
   // totals of every class and the counts of the blocks before this one
   unsigned tot[PROBE_CLASSES] = {0, 0, 0, 0}, before[PROBE_CLASSES] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < nb; b += 256)
@@ -1282,10 +1289,11 @@ __global__ void resolve_kernel(const RenderParams P) {
     int py = (gtile / P.tiles_x) * P.tile_h + pit / P.tile_w;
     if (px >= P.W || py >= P.H) continue;
     // exact sum of all the pixel's contributions, rounded once to fp32
-    const long long *a = P.acc + i * 3;
+    long long *a = P.acc + i * 3;
     float r = (float)((double)a[0] * 9.094947017729282e-13);  // 2^-40
     float g = (float)((double)a[1] * 9.094947017729282e-13);
     float b = (float)((double)a[2] * 9.094947017729282e-13);
+    a[0] = a[1] = a[2] = 0;  // the next frame's sums start from zero (no separate 50 MB clear)
     float nf = (float)P.spp;
     size_t o3 = P.compact ? i * 3 : ((size_t)py * P.W + px) * 3;
     P.rgb[o3 + 0] = r / nf;
