@@ -249,6 +249,7 @@ def main() -> None:
         # the per-kernel duration is no longer the per-frame cost; `value` is the throughput.)
         r, stream = df.r, df.streams[0].cuda_stream
         r.set_concurrency(1)   # the whole GPU for the one frame in flight
+        r.set_timing(True)     # the library's events around render_kernel
         kms, lms = [], []
         for _ in range(args.steps):
             r.render_async(df.frames[0].data_ptr(), 0, args.flags, stream)

@@ -114,7 +114,7 @@ DEVICE_SYMBOLS = [
     "rt_init", "rt_shutdown", "rt_upload_scene", "rt_set_camera", "rt_set_samples",
     "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
-    "rt_wave_diag", "rt_get_stream", "rt_set_concurrency",
+    "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -225,6 +225,7 @@ def device_lib() -> C.CDLL:
         L.rt_wave_diag.argtypes = [vp, C.POINTER(u64), i32]
         L.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.rt_set_concurrency.argtypes = [vp, i32]
+        L.rt_set_timing.argtypes = [vp, i32]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
         L.rt_abi_version.restype = C.c_int
@@ -472,6 +473,10 @@ class Renderer:
 
     def set_concurrency(self, n_concurrent: int) -> None:
         self._check(self.lib.rt_set_concurrency(self._h, n_concurrent), "rt_set_concurrency")
+
+    def set_timing(self, on: bool) -> None:
+        """Record (default) or skip the events behind Stats.ms_launch / ms_kernel."""
+        self._check(self.lib.rt_set_timing(self._h, 1 if on else 0), "rt_set_timing")
 
     def tiling(self) -> Tiling:
         t = Tiling()

@@ -48,6 +48,7 @@ struct rt_ctx {
   size_t scratch_floats = 0;
   unsigned long long scratch_stride = 0;
   int scratch_waves = 0;
+  bool timing = true;      // record the events behind rt_stats.ms_launch / ms_kernel (rt_set_timing)
   bool acc_clean = false;  // every pixel sum of d_acc is zero (left so by resolve_kernel)
   unsigned *d_tile_counter = nullptr;
   unsigned long long *d_stats = nullptr;
@@ -377,8 +378,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   cfg.mlight = c->n_lights > 1;
   p.point_words = cfg.mlight ? POINT_WORDS : 0;
   cfg.lds_bytes = lds_bytes_for(c->stack_depth, p.point_words);
-  cfg.ev_k0 = c->evk0;
-  cfg.ev_k1 = c->evk1;
+  cfg.ev_k0 = c->timing ? c->evk0 : nullptr;
+  cfg.ev_k1 = c->timing ? c->evk1 : nullptr;
   cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
   cfg.count = (flags & RT_FLAG_COUNT_TESTS) != 0;
   // Small scenes (every shipped benchmark scene but bench3) are staged into each block's LDS:
@@ -453,13 +454,13 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (!c->acc_clean)
     HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, c->acc_samples * 3 * sizeof(long long), s));
   c->acc_clean = false;
-  HIP_TRY(c, hipEventRecord(c->ev0, s));
+  if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
   HIP_TRY(c, hipGetLastError());
   c->acc_clean = true;  // resolve_kernel is enqueued: it leaves every sum it reads at zero
-  HIP_TRY(c, hipEventRecord(c->ev1, s));
-  c->timed = true;
+  if (c->timing) HIP_TRY(c, hipEventRecord(c->ev1, s));
+  c->timed = c->timing;
   return RT_OK;
 }
 
@@ -690,6 +691,12 @@ int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, 
   int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, s, d_rgb, d_rgb8, n);
   HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_set_timing(rt_ctx *c, int32_t on) {
+  if (!c) return RT_ERR_INVALID;
+  c->timing = on != 0;
   return RT_OK;
 }
 

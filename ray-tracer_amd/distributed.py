@@ -70,6 +70,8 @@ class DistributedFrame:
         self.rank, self.nranks, self.device = rank, nranks, device
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
+        for r in self.renderers:
+            r.set_timing(False)   # throughput contexts: four stream operations per frame, not eight
         self.rehearsal = rehearse_share is not None
         self.tune_worlds = tune_worlds
         for r in self.renderers:
