@@ -575,7 +575,7 @@ DEVI void packet_src_init(const RenderParams &P, PacketSrc &ps, int shard) {
   ps.pending = false;
   ps.pend_want = 0;
   ps.pend_got = 0;
-  ps.n_entries = (long long)P.class_totals[4];
+  ps.n_entries = P.n_packets > 0 ? (long long)P.class_totals[4] : 0;  // (no packets: order_kernel did not run)
   ps.per_shard = (int)((ps.n_entries + PACKET_SHARDS - 1) / PACKET_SHARDS);
   ps.refr_entries = (long long)P.class_totals[5];
   ps.refl_end = ps.refr_entries + (long long)P.class_totals[2];
