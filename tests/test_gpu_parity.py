@@ -317,3 +317,25 @@ def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth):
         sl = slice(r0 * W, (r0 + n_rows) * W)
         assert int((a_ids[sl] != o_ids[sl]).sum()) == 0
         check_image(rt, a_rgb[sl], o_rgb[sl])
+
+
+def test_rank_without_tiles_renders_nothing(rt, renderer):
+    """More ranks than tiles: a rank whose share is empty launches with zero packets right after
+    a frame that had some; it must trace nothing (and not pick up the previous frame's packet
+    order)."""
+    import torch
+    w = make_world(rt, "bench1", 40, 24, 4)
+    grids = rt.generate_grids(9, w.width + 10, w.camera.aa)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    renderer.set_partition(0, 1)
+    _, _, full = renderer.render(0)
+    assert full.rays_total > 0
+    n_tiles = renderer.tiling().n_tiles
+    buf = torch.zeros(w.height * w.width * 3 + 4096, dtype=torch.float32, device="cuda:0")
+    renderer.set_partition(n_tiles, n_tiles + 1)     # the rank after the last tile's owner
+    assert renderer.tiling().n_local_tiles == 0
+    renderer.render_tiles_async(buf.data_ptr())
+    st = renderer.collect()
+    renderer.set_partition(0, 1)
+    assert st.rays_total == 0 and not buf.any().item()
