@@ -116,10 +116,21 @@ def cpu_baseline(world, grids, seconds_target: float = 25.0):
         if time.perf_counter() - t0 > seconds_target:
             break
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"{rows} of {H} rows of the same frame (27-row stripes every 54 rows), "
-                      f"{rays} rays in {dt:.1f} s; reference ray accounting (every reflection ray "
-                      "traced); restatement of the reference algorithm, not the Haskell binary"}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": f"{rows} of {H} rows of the same frame (27-row stripes every 54 rows), "
+                     f"{rays} rays in {dt:.1f} s; reference ray accounting (every reflection ray "
+                     "traced); restatement of the reference algorithm, not the Haskell binary"}
+    # Beside it: the same restatement with OpenMP over rows on the host cores of this
+    # box's share -- what a parallel CPU port would reach; the reference itself is sequential.
+    threads = max(1, min(16, ob.lib().rto_max_threads(), os.cpu_count() or 1))
+    if threads > 1:
+        a, b = stripes[len(stripes) // 2][0], min(H, stripes[len(stripes) // 2][0] + 216)
+        t1 = time.perf_counter()
+        _, _, st = ob.render(world, grids, 0, rows=(a, b), threads=threads, want_hit_ids=False)
+        dt1 = time.perf_counter() - t1
+        out["all_cores"] = {"value": st.rays_total / dt1 / 1e6, "unit": "Mrays/s", "cores": threads,
+                            "sample": f"rows {a}..{b - 1} of the same frame, {st.rays_total} rays in {dt1:.1f} s"}
+    return out
 
 
 def main() -> None:
@@ -263,6 +274,10 @@ def main() -> None:
         tf = flops / (kernel_ms * 1e-3) / 1e12
         gbps = rays_frame * BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
         out["config"]["frame_latency_ms"] = round(float(np.mean(lms)), 4)
+        # the reference traces more rays than the default policy launches (every reflection ray,
+        # every light's shadow ray): state that count beside the one `value` is based on
+        r.render_async(df.frames[0].data_ptr(), 0, args.flags | rt.FLAG_TRACE_ZERO_WEIGHT, stream)
+        out["config"]["rays_per_frame_reference_accounting"] = int(r.collect(stream).rays_total)
         traffic, traffic_src = pmc_traffic(args.workload)
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(tf, 3), "peak": PEAK_VALU_TFLOPS,
