@@ -145,6 +145,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="self-test: run the gather/assemble path with one rank and check the frame")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "frames"],
+                    help="N > 1: 'tiles' = every frame split over the ranks + RCCL gather (default); 'frames' "
+                         "(animation, SURVEY 8e / config 5) = rank r renders whole frames r, r+N, ... with no "
+                         "data-path collective")
     ap.add_argument("--rehearse-share", default=None, metavar="R/N",
                     help="one-GPU timing rehearsal of rank R's share of an N-rank job (no collective); "
                          "the line then reports that share's rays only")
@@ -177,7 +181,9 @@ def main() -> None:
 
     # F contexts render alternate frames on their own streams (ray-tracer_amd/distributed.py):
     # the next frame's blocks fill the wave slots the current frame's tail leaves empty
-    df = rtd.DistributedFrame(make_renderer, rank, world_size, dev, in_flight=args.frames_in_flight,
+    by_frames = args.shard == "frames" and world_size > 1
+    df = rtd.DistributedFrame(make_renderer, 0 if by_frames else rank, 1 if by_frames else world_size, dev,
+                              in_flight=args.frames_in_flight,
                               force_collective=args.force_collective, share_gpu=args.share_gpu,
                               rehearse_share=tuple(int(x) for x in args.rehearse_share.split("/"))
                               if args.rehearse_share else None,
@@ -196,7 +202,9 @@ def main() -> None:
     def submit():
         if animated:
             frame_no[0] += 1
-            df.submit(args.flags, make_world(args.workload, float(frame_no[0])))
+            # frame index: this rank's own sequence, or every world_size-th frame of the job's
+            k = frame_no[0] * world_size + rank if by_frames else frame_no[0]
+            df.submit(args.flags, make_world(args.workload, float(k)))
         else:
             df.submit(args.flags)
 
@@ -237,11 +245,16 @@ def main() -> None:
                        "rays_primary": int(rays[1].item()), "rays_shadow": int(rays[2].item()),
                        "rays_bounce": int(rays[3].item()),
                        "frames_in_flight": df.mode[0], "grid_fraction_per_context": f"1/{df.mode[1]}",
-                       "parallelism": f"tiles%{world_size}" + ("+rccl_gather" if world_size > 1 else ""),
+                       "parallelism": (f"frames%{world_size} (whole frames per rank, no collective)" if by_frames
+                                       else f"tiles%{world_size}" + ("+rccl_gather" if world_size > 1 else "")),
                        "sample_seed": SEED},
         }
         if args.rehearse_share:
             out["config"]["rehearsal_of_rank_share"] = args.rehearse_share
+        if by_frames:
+            # a step = one frame on EVERY rank (world_size frames); per-GPU work is fixed as N grows
+            out["scaling"] = "weak"
+            out["config"]["frames_per_step"] = world_size
     if args.force_collective:
         ref = torch.zeros_like(df.frames[0])
         df.r.set_partition(0, 1)
