@@ -14,7 +14,7 @@
 //     (<= 191 rays per level);
 //   * BVH traversal (hitBVH/hits/hitsBox) keeps its per-lane stack in LDS;
 //   * recursion is flattened to weight-carrying rays: colour(sample) =
-//     sum over its rays of weight * direct colour, accumulated EXACTLY (2^-40 fixed
+//     sum over its rays of weight * direct colour, accumulated EXACTLY (2^-34 fixed
 //     point) in a per-pixel buffer (L2-resident), so the frame is bitwise independent of the
 //     scheduling; resolve_kernel then forms the pixel average (avgColors).
 //
@@ -524,15 +524,18 @@ constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 #define RT_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
 
-// Exact, order-independent accumulation: a contribution is converted to 2^-40 fixed
+// Exact, order-independent accumulation: a contribution is converted to 2^-34 fixed
 // point (int64); integer addition is associative, so a pixel's sum does not depend
 // on the order in which the scheduler happens to process its rays (bitwise
-// reproducible frames, identical for every tile partition).  Range +-2^23; a
-// non-finite contribution (the reference can produce k = +inf, RayTracer.hs:141)
-// saturates to +-2^22 and is therefore still clamped to 0 / 1 by writePPM.
+// reproducible frames, identical for every tile partition).  A contribution is limited to
+// +-2^12, i.e. +-2^46 in fixed point: a pixel's at most 2^16 contributions (1024 samples x
+// 63 rays of a depth-6 tree) cannot overflow the 64-bit sum, and one saturated sample still
+// drives the pixel average to >= 4 > 1 at 1024 spp.  A non-finite contribution (the reference
+// can produce k = +inf, RayTracer.hs:141) therefore saturates and is still clamped to 0 / 1
+// by writePPM.
 DEVI long long to_fixed(float c) {
-  c = fminf(fmaxf(c, -4194304.0f), 4194304.0f);
-  return (long long)(c * 1099511627776.0f);
+  c = fminf(fmaxf(c, -4096.0f), 4096.0f);
+  return (long long)(c * 17179869184.0f);  // 2^34
 }
 
 // Data-parallel-primitive move of a 64-bit value: lane i receives the value of the lane that
@@ -1290,9 +1293,9 @@ __global__ void resolve_kernel(const RenderParams P) {
     if (px >= P.W || py >= P.H) continue;
     // exact sum of all the pixel's contributions, rounded once to fp32
     long long *a = P.acc + i * 3;
-    float r = (float)((double)a[0] * 9.094947017729282e-13);  // 2^-40
-    float g = (float)((double)a[1] * 9.094947017729282e-13);
-    float b = (float)((double)a[2] * 9.094947017729282e-13);
+    float r = (float)((double)a[0] * 5.820766091346741e-11);  // 2^-34
+    float g = (float)((double)a[1] * 5.820766091346741e-11);
+    float b = (float)((double)a[2] * 5.820766091346741e-11);
     a[0] = a[1] = a[2] = 0;  // the next frame's sums start from zero (no separate 50 MB clear)
     float nf = (float)P.spp;
     size_t o3 = P.compact ? i * 3 : ((size_t)py * P.W + px) * 3;

@@ -339,3 +339,23 @@ def test_rank_without_tiles_renders_nothing(rt, renderer):
     st = renderer.collect()
     renderer.set_partition(0, 1)
     assert st.rays_total == 0 and not buf.any().item()
+
+
+def test_huge_contributions_saturate_without_overflow(rt, oracle, renderer):
+    """A light of colour 1e37 makes every lit sample's contribution astronomically large (the
+    reference's float sum goes to inf, writePPM's clamp prints 255).  The GPU's fixed-point
+    pixel sums limit each contribution instead; 16 samples x several rays of them must not
+    wrap the 64-bit sum around: the 8-bit frame equals the oracle's everywhere."""
+    s = rt.Scene.builtin("bench5")
+    l = rt.Light((f32 * 3)(0, 30, 0), (f32 * 3)(0, 0, 0), (f32 * 3)(0, 0, 0), (f32 * 3)(1e37, 1e37, 1e37))
+    rt.host_lib().rth_scene_add_light(s._h, C.byref(l))
+    s.build_bvh("sah")
+    cfg = rt.default_config("bench5")
+    cfg.image_width, cfg.image_height, cfg.anti_aliasing = 48, 32, 16
+    w = rt.config_to_world(cfg, s)
+    (g_rgb, g_ids, _), (o_rgb, o_ids, _) = run_both(rt, oracle, renderer, w, 2, 0, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0
+    g8, o8 = rt.quantize(g_rgb), rt.quantize(o_rgb)
+    assert (o8 == 255).mean() > 0.1          # the lit part of the scene really is blown out
+    ok = ~np.isnan(o_rgb)
+    assert np.array_equal(g8[ok], o8[ok])
