@@ -29,6 +29,8 @@ struct rt_ctx {
   float4 *d_nodes = nullptr, *d_prims = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
   size_t cap_nodes = 0, cap_prims = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
+  void *h_stage = nullptr;  // pinned staging buffer of the uploads
+  size_t stage_cap = 0;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
@@ -108,15 +110,29 @@ int upload(rt_ctx *c, T **dst, size_t *cap, const void *src, size_t bytes) {
       *dst = nullptr;
       *cap = 0;
     }
-    HIP_TRY(c, hipMalloc((void **)dst, bytes));
-    *cap = bytes;
+    // (with headroom: an animated scene's tree changes shape from frame to frame, and growing by
+    //  a few records must not mean a hipFree -- a device-wide wait of tens of milliseconds)
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+    HIP_TRY(c, hipMalloc((void **)dst, want));
+    *cap = want;
   }
   if (src) {
     // a frame enqueued on a caller's stream is not ordered before c->stream: wait for it first
     if (c->last_launch_stream && c->last_launch_stream != c->stream)
       HIP_TRY(c, hipStreamSynchronize(c->last_launch_stream));
-    HIP_TRY(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // through the context's own pinned staging buffer, so that the copy is a plain DMA on this
+    // stream and never depends on how the runtime stages pageable memory
+    if (c->stage_cap < bytes) {
+      if (c->h_stage) (void)hipHostFree(c->h_stage);
+      c->h_stage = nullptr;
+      c->stage_cap = 0;
+      size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+      HIP_TRY(c, hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
+      c->stage_cap = cap;
+    }
+    std::memcpy(c->h_stage, src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(*dst, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
   }
   return RT_OK;
 }
@@ -546,6 +562,7 @@ void rt_shutdown(rt_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evk0) (void)hipEventDestroy(c->evk0);
   if (c->evk1) (void)hipEventDestroy(c->evk1);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -16,6 +16,8 @@ torch is used for device memory, streams and torch.distributed only.
 """
 from __future__ import annotations
 
+import os
+import sys
 from typing import List, Optional, Tuple
 
 import torch
@@ -136,6 +138,9 @@ class DistributedFrame:
                 torch.cuda.synchronize(self.device)
                 times.append(time.perf_counter() - t0)
             t = min(times[1:])
+            if os.environ.get("RT_TUNE_DEBUG"):
+                print(f"[tune] in flight {depth}, grid 1/{div}: " + " ".join(f"{x / n_frames * 1e3:.3f}" for x in times) + " ms/frame",
+                      file=sys.stderr, flush=True)
             if best is None or t < best[0] * 0.99:   # prefer the simpler mode unless 1 % faster
                 best = (t, depth, div)
         _, depth, div = best
