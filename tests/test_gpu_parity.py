@@ -359,3 +359,35 @@ def test_huge_contributions_saturate_without_overflow(rt, oracle, renderer):
     assert (o8 == 255).mean() > 0.1          # the lit part of the scene really is blown out
     ok = ~np.isnan(o_rgb)
     assert np.array_equal(g8[ok], o8[ok])
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the keys the driver reads, plus `roofline` and
+    `cpu_baseline` (run on the small reference configuration so that it takes seconds)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "5",
+                        "--warmup", "2"], capture_output=True, text=True, timeout=170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"]
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+    assert abs(j["value"] - j["config"]["rays_per_frame"] / j["ms_per_step"] / 1e3) < 0.01 * j["value"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel_ms"] > 0
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert j["config"]["rays_per_frame_reference_accounting"] >= j["config"]["rays_per_frame"]
