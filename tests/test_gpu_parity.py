@@ -391,3 +391,31 @@ def test_bench_line_contract():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert j["config"]["rays_per_frame_reference_accounting"] >= j["config"]["rays_per_frame"]
+
+
+def test_boundary_reports_misuse_as_errors(rt):
+    """The C ABI never aborts: calls out of order or with inconsistent inputs come back as
+    negative status codes with a message (RtError in the Python mirror), and the context stays
+    usable afterwards."""
+    import torch
+    r = rt.Renderer(0)
+    try:
+        buf = torch.zeros(64 * 48 * 3, dtype=torch.float32, device="cuda:0")
+        with pytest.raises(rt.RtError, match="rt_upload_scene"):
+            r.render_async(buf.data_ptr(), 0, 0)                    # nothing uploaded yet
+        w = make_world(rt, "bench5", 64, 48, 4)
+        r.set_world(w)
+        with pytest.raises(rt.RtError, match="rt_set_samples"):
+            r.render_async(buf.data_ptr(), 0, 0)                    # no sample table yet
+        r.set_samples(rt.generate_grids(1, 74, 1))                  # 1 sample per pixel, camera wants 4
+        with pytest.raises(rt.RtError, match="spp"):
+            r.render_async(buf.data_ptr(), 0, 0)
+        with pytest.raises(rt.RtError):
+            r.set_partition(3, 2)                                   # rank outside 0..nranks-1
+        with pytest.raises(rt.RtError):
+            r.set_concurrency(0)
+        r.set_samples(rt.generate_grids(1, 74, 2))                  # now consistent: the context still works
+        rgb, _, st = r.render(0)
+        assert st.rays_primary == 64 * 48 * 4 and np.isfinite(rgb).all()
+    finally:
+        r.close()
