@@ -419,3 +419,38 @@ def test_boundary_reports_misuse_as_errors(rt):
         assert st.rays_primary == 64 * 48 * 4 and np.isfinite(rgb).all()
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("damage,needle", [
+    ("child", "child index out of range"),
+    ("cycle", "reachable twice"),
+    ("leaf", "leaf range out of bounds"),
+    ("material", "material index out of range"),
+])
+def test_upload_rejects_a_malformed_scene(rt, damage, needle):
+    """rt_upload_scene walks the flattened BVH it is handed (the Haskell host's, in a deployment)
+    and refuses what the kernels could not traverse safely, instead of faulting on the GPU."""
+    from types import SimpleNamespace
+    w = make_world(rt, "bench1", 32, 24, 1)
+    v = w.scene.view
+    nodes = (rt.BvhNode * v.n_nodes)(*[v.nodes[i] for i in range(v.n_nodes)])
+    tris = (rt.Triangle * max(1, v.n_triangles))(*[v.triangles[i] for i in range(v.n_triangles)])
+    inner = next(i for i in range(v.n_nodes) if nodes[i].left >= 0)
+    leaf = next(i for i in range(v.n_nodes) if nodes[i].left < 0)
+    if damage == "child":
+        nodes[inner].right = v.n_nodes + 5
+    elif damage == "cycle":
+        nodes[inner].right = nodes[inner].left
+    elif damage == "leaf":
+        nodes[leaf].right = v.n_refs + 1
+    else:
+        tris[0].material = v.n_materials
+    bad = rt.SceneView(nodes, v.n_nodes, v.leaf_refs, v.n_refs, v.spheres, v.n_spheres, tris, v.n_triangles,
+                       v.materials, v.n_materials, v.lights, v.n_lights)
+    r = rt.Renderer(0)
+    try:
+        with pytest.raises(rt.RtError, match=needle):
+            r.set_world(SimpleNamespace(scene=SimpleNamespace(view=bad), camera=w.camera))
+        r.set_world(w)   # the context is still good for a well-formed scene
+    finally:
+        r.close()
