@@ -24,7 +24,7 @@ class OracleStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_shadow", u64), ("rays_reflection", u64),
                 ("rays_refraction", u64), ("box_tests", u64), ("sphere_tests", u64),
                 ("triangle_tests", u64), ("primary_hits", u64), ("nan_hits", u64),
-                ("nonfinite_samples", u64)]
+                ("nonfinite_samples", u64), ("exit_branch", u64), ("tir", u64)]
 
     @property
     def rays_total(self) -> int:

@@ -35,6 +35,8 @@ typedef struct rto_stats {
   uint64_t primary_hits;
   uint64_t nan_hits;          /* hit records whose t is NaN (tie rule differs) */
   uint64_t nonfinite_samples; /* samples whose colour has an inf/NaN channel   */
+  uint64_t exit_branch;       /* getIndirectColor took the leaving-the-medium branch (dn >= 0, :140-145) */
+  uint64_t tir;               /* ... and refract reported total internal reflection there (:144)          */
 } rto_stats;
 
 typedef struct { float x, y, z; } vec3;
@@ -284,6 +286,8 @@ static color indirect_color(octx *o, int depth, float s0, float s1, vec3 dir, ve
       has_t = refract(dir, normal, nt, &tdir);
     } else {
       has_t = refract(dir, multiply(normal, -1), 1 / nt, &tdir);
+      o->st.exit_branch++;
+      if (!has_t) o->st.tir++;
       const float *at = mt->log_atten;
       k = col(expf(-at[0]), expf(-at[1]), expf(-at[2]));
       c = has_t ? dot(tdir, normal) : 0;

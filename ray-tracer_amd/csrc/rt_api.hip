@@ -22,6 +22,7 @@ struct rt_ctx {
   hipStream_t stream = nullptr;
   hipStream_t last_launch_stream = nullptr;  // where the newest frame was enqueued (caller's or ours)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+  hipEvent_t evt0 = nullptr, evt1 = nullptr;  // rt_render's whole-call bracket (ms_total)
   bool timed = false;
   std::string err;
 
@@ -333,6 +334,12 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   int rc = prepare(c, flags);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
+  // A context owns ONE set of per-frame work buffers (pixel sums, ticket counters, packet order,
+  // ray queues): it has one frame in flight.  Frames on the same stream are ordered by the stream;
+  // a frame enqueued on ANOTHER stream than the previous one first waits for that one (rare: a
+  // caller alternating streams on one context -- use one context per stream to overlap frames).
+  if (c->last_launch_stream && c->last_launch_stream != s) HIP_TRY(c, hipStreamSynchronize(c->last_launch_stream));
+  c->last_launch_stream = s;
   const rt_camera &cam = c->cam;
   RenderParams p{};
   p.nodes = c->d_nodes;
@@ -426,8 +433,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
                    (c->five_waves_mode > 0 ||
                     (c->five_waves_mode < 0 && (long long)p.n_packets >= 64ll * c->n_cus * 20));
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  int per_cu = fma ? occupancy_fma(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes)
-                   : occupancy_strict(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes);
+  cfg.probe_lds_bytes = lds_bytes_for(c->stack_depth, p.point_words, WAVES_PER_BLOCK);
+  int per_cu = fma ? occupancy_fma(cfg) : occupancy_strict(cfg);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + wpb - 1) / wpb;
@@ -539,6 +546,7 @@ int rt_init(int device, rt_ctx **out) {
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
+            hipEventCreate(&c->evt0) == hipSuccess && hipEventCreate(&c->evt1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
             hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 32) * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
@@ -562,6 +570,8 @@ void rt_shutdown(rt_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evk0) (void)hipEventDestroy(c->evk0);
   if (c->evk1) (void)hipEventDestroy(c->evk1);
+  if (c->evt0) (void)hipEventDestroy(c->evt0);
+  if (c->evt1) (void)hipEventDestroy(c->evt1);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -668,14 +678,12 @@ int rt_get_tiling(rt_ctx *c, rt_tiling *out) {
 int rt_render_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_ids, void *stream) {
   if (!c || !d_rgb) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_launch_stream = s;
   return launch(c, flags, d_rgb, 0, d_ids, s);
 }
 
 int rt_render_tiles_async(rt_ctx *c, uint32_t flags, float *d_tiles, void *stream) {
   if (!c || !d_tiles) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_launch_stream = s;
   return launch(c, flags, d_tiles, 1, nullptr, s);
 }
 
@@ -751,9 +759,9 @@ int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_s
   int rc = prepare(c, flags);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
-  hipEvent_t t0, t1;
-  HIP_TRY(c, hipEventCreate(&t0));
-  HIP_TRY(c, hipEventCreate(&t1));
+  // (the two events of the whole-call bracket live in the context: nothing to leak on the
+  //  error returns below)
+  hipEvent_t t0 = c->evt0, t1 = c->evt1;
   size_t npx = (size_t)c->cam.img_w * c->cam.img_h;
   if (c->d_rgb_floats < npx * 3) {
     if (c->d_rgb) (void)hipFree(c->d_rgb);
@@ -786,8 +794,6 @@ int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_s
     HIP_TRY(c, hipEventElapsedTime(&ms, t0, t1));
     st->ms_total = ms;
   }
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
   return RT_OK;
 }
 

@@ -95,13 +95,14 @@ struct LaunchCfg {
   bool five_waves;          // the 96-VGPR build: LDS scene of <= 32 KB per block, one light, pruned, uncounted
   bool mlight;              // more than one light: the build with the shadow-ray pool (pruned, uncounted launches)
   size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
+  size_t probe_lds_bytes;   // probe_kernel: the traversal stacks of its own four waves
 };
 
 // one per arithmetic mode (separate translation units, different -ffp-contract)
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
-int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes);
-int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes);
+int occupancy_strict(const LaunchCfg &cfg);  // resident blocks per CU of the kernel cfg selects
+int occupancy_fma(const LaunchCfg &cfg);
 
 inline size_t lds_bytes_for(int stack_depth, int point_words, int waves_per_block = WAVES_PER_BLOCK) {
   return (size_t)waves_per_block * (size_t)(stack_depth * 64 + point_words + 32) * 4;

@@ -549,11 +549,14 @@ constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 // reproducible frames, identical for every tile partition).  A contribution is limited to
 // +-2^12, i.e. +-2^46 in fixed point: a pixel's at most 2^16 contributions (1024 samples x
 // 63 rays of a depth-6 tree) cannot overflow the 64-bit sum, and one saturated sample still
-// drives the pixel average to >= 4 > 1 at 1024 spp.  A non-finite contribution (the reference
-// can produce k = +inf, RayTracer.hs:141) therefore saturates and is still clamped to 0 / 1
-// by writePPM.
+// drives the pixel average to >= 4 > 1 at 1024 spp.  A non-finite contribution therefore saturates:
+// +-inf (the reference can produce k = +inf, RayTracer.hs:141) to +-2^12, still clamped to 1 / 0
+// by writePPM like the reference's inf; NaN (that weight times a zero colour: inf * 0) to +2^12 --
+// fmaxf/fminf would DROP a NaN operand and turn it into -2^12, cancelling a sibling's +2^12.  The
+// reference's pixel is NaN in that case and `truncate NaN` is garbage (Main.hs:131), so there is no
+// value to match; NaN pixels are excluded from parity and counted by the oracle.
 DEVI long long to_fixed(float c) {
-  c = fminf(fmaxf(c, -4096.0f), 4096.0f);
+  c = (c != c) ? 4096.0f : fminf(fmaxf(c, -4096.0f), 4096.0f);
   return (long long)(c * 17179869184.0f);  // 2^34
 }
 
@@ -1324,50 +1327,66 @@ __global__ void resolve_kernel(const RenderParams P) {
   }
 }
 
-template <bool PRUNE, bool COUNT>
-static void launch_t(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
-  if (cfg.block == 512) {  // LDS scene, pruned, uncounted (chosen by the host only then)
-    // more than 64 KB of dynamic LDS has to be asked for (per device; a cheap host-side call)
-    if (cfg.mlight) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, true, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-      hipLaunchKernelGGL((render_kernel<true, false, true, true, 8>), dim3(cfg.grid), dim3(512), cfg.lds_bytes, s, p);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, false, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-      hipLaunchKernelGGL((render_kernel<true, false, true, false, 8>), dim3(cfg.grid), dim3(512), cfg.lds_bytes, s, p);
-    }
-  } else if (cfg.mlight && PRUNE && !COUNT) {
-    if (cfg.lds_scene)
-      hipLaunchKernelGGL((render_kernel<true, false, true, true>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
-    else
-      hipLaunchKernelGGL((render_kernel<true, false, false, true>), dim3(cfg.grid), dim3(cfg.block),
-                         cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
-  } else if (cfg.five_waves)
-    hipLaunchKernelGGL((render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
-  else if (cfg.lds_scene && !COUNT)
-    hipLaunchKernelGGL((render_kernel<PRUNE, false, true, false>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, p);
-  else
-    hipLaunchKernelGGL((render_kernel<PRUNE, COUNT, false, false>), dim3(cfg.grid), dim3(cfg.block),
-                       cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
+// More than 64 KB of dynamic LDS (deep trees: the per-lane traversal stacks; the 8-wave blocks
+// that share one scene copy) has to be asked for, per kernel and device; a cheap host-side call.
+template <class K>
+static void allow_lds(K kernel, size_t lds_bytes) {
+  if (lds_bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+}
+template <class K>
+static void launch_k(K kernel, int grid, int block, size_t lds_bytes, hipStream_t s, const RenderParams &p) {
+  allow_lds(kernel, lds_bytes);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, s, p);
+}
+template <class K>
+static int occupancy_k(K kernel, int block, size_t lds_bytes) {
+  int n = 0;
+  allow_lds(kernel, lds_bytes);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, lds_bytes) == hipSuccess ? n : 0;
+}
+
+// The instantiation the host's choices (rt_api.hip launch()) select; F is called with the kernel
+// and the dynamic LDS it needs, so that launch and occupancy query cannot disagree.
+template <class F>
+static auto with_render_kernel(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block,
+                               size_t lds_bytes, size_t lds_scene_bytes, F f) {
+  const size_t no_scene = lds_bytes - lds_scene_bytes;
+  if (block == 512) {  // LDS scene shared by two 8-wave blocks per CU; pruned, uncounted (host only picks it then)
+    if (mlight) return f(&render_kernel<true, false, true, true, 8>, lds_bytes);
+    return f(&render_kernel<true, false, true, false, 8>, lds_bytes);
+  }
+  if (mlight && prune && !count) {
+    if (lds_scene) return f(&render_kernel<true, false, true, true>, lds_bytes);
+    return f(&render_kernel<true, false, false, true>, no_scene);
+  }
+  if (five_waves) return f(&render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>, lds_bytes);
+  if (lds_scene && !count) {
+    if (prune) return f(&render_kernel<true, false, true, false>, lds_bytes);
+    return f(&render_kernel<false, false, true, false>, lds_bytes);
+  }
+  if (prune) {
+    if (count) return f(&render_kernel<true, true, false, false>, no_scene);
+    return f(&render_kernel<true, false, false, false>, no_scene);
+  }
+  if (count) return f(&render_kernel<false, true, false, false>, no_scene);
+  return f(&render_kernel<false, false, false, false>, no_scene);
 }
 
 static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   if (p.n_packets > 0) {
-    if (cfg.prune)
-      hipLaunchKernelGGL((probe_kernel<true>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
-    else
-      hipLaunchKernelGGL((probe_kernel<false>), dim3(p.probe_blocks), dim3(256), cfg.lds_bytes - cfg.lds_scene_bytes, s, p);
+    // probe_kernel: 4 waves per block, traversal stacks only (it reads the scene from memory)
+    if (cfg.prune) launch_k(&probe_kernel<true>, p.probe_blocks, 256, cfg.probe_lds_bytes, s, p);
+    else launch_k(&probe_kernel<false>, p.probe_blocks, 256, cfg.probe_lds_bytes, s, p);
     hipLaunchKernelGGL(order_kernel, dim3(p.probe_blocks), dim3(256), 0, s, p);
   }
   if (cfg.ev_k0) (void)hipEventRecord(cfg.ev_k0, s);  // around the trace/shade kernel alone
-  if (cfg.prune) {
-    if (cfg.count) launch_t<true, true>(p, cfg, s);
-    else launch_t<true, false>(p, cfg, s);
-  } else {
-    if (cfg.count) launch_t<false, true>(p, cfg, s);
-    else launch_t<false, false>(p, cfg, s);
-  }
+  with_render_kernel(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
+                     cfg.lds_scene_bytes, [&](auto kernel, size_t lds) {
+                       launch_k(kernel, cfg.grid, cfg.block, lds, s, p);
+                       return 0;
+                     });
   if (cfg.ev_k1) (void)hipEventRecord(cfg.ev_k1, s);
   size_t total = (size_t)p.n_local_tiles * p.tile_w * p.tile_h;
   if (total) {
@@ -1377,36 +1396,10 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
-  int n = 0;
-  hipError_t e;
-  if (block == 512) {
-    // (more than 64 KB of dynamic LDS has to be allowed before it can be asked about or launched)
-    if (mlight) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, true, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true, 8>, 512, lds_bytes);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, false, true, false, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, 8>, 512, lds_bytes);
-    }
-  } else if (five_waves) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false, WAVES_PER_BLOCK, 5>, 256, lds_bytes);
-  } else if (mlight && prune && !count) {
-    if (lds_scene) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, true>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, true>, 256, lds_bytes);
-  } else if (lds_scene && !count) {
-    if (prune) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, true, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, true, false>, 256, lds_bytes);
-  } else if (prune) {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, false, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, false, false, false>, 256, lds_bytes);
-  } else {
-    if (count) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, true, false, false>, 256, lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, false, false, false>, 256, lds_bytes);
-  }
-  return e == hipSuccess ? n : 0;
+static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes,
+                     size_t lds_scene_bytes) {
+  return with_render_kernel(prune, count, lds_scene, mlight, five_waves, block, lds_bytes, lds_scene_bytes,
+                            [&](auto kernel, size_t lds) { return occupancy_k(kernel, block, lds); });
 }
 
 }  // namespace RT_NS

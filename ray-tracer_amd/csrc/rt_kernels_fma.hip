@@ -9,7 +9,8 @@ namespace rtdev {
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   fma::launch(p, cfg, s);
 }
-int occupancy_fma(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
-  return fma::occupancy(prune, count, lds_scene, mlight, five_waves, block, lds_bytes);
+int occupancy_fma(const LaunchCfg &cfg) {
+  return fma::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
+                           cfg.lds_scene_bytes);
 }
 }  // namespace rtdev

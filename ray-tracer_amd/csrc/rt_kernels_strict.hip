@@ -8,7 +8,8 @@ namespace rtdev {
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   strict::launch(p, cfg, s);
 }
-int occupancy_strict(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes) {
-  return strict::occupancy(prune, count, lds_scene, mlight, five_waves, block, lds_bytes);
+int occupancy_strict(const LaunchCfg &cfg) {
+  return strict::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
+                           cfg.lds_scene_bytes);
 }
 }  // namespace rtdev

@@ -31,6 +31,15 @@ def partition_layout(n_tiles: int, tile_w: int, tile_h: int, nranks: int) -> Tup
     return tile_floats, ((n_tiles + nranks - 1) // nranks) * tile_floats
 
 
+def compact_floats(tiling) -> int:
+    """Floats rt_render_tiles_async writes for a context whose rt_get_tiling is `tiling`:
+    n_local_tiles whole tiles.  The tile grid is padded to whole tiles, so with one rank this
+    EXCEEDS img_w * img_h * 3 whenever the image sides are not multiples of the tile sides
+    (800x600 at 1 spp: 25 x 19 tiles of 32 x 32 pixels = 1 459 200 floats for a 1 440 000-float
+    frame) -- every buffer handed to render_tiles_async is sized with this, never from W * H."""
+    return tiling.n_local_tiles * tiling.tile_w * tiling.tile_h * 3
+
+
 def gather_tiles(mine: torch.Tensor, gathered: Optional[torch.Tensor], dst: int = 0,
                  async_op: bool = False):
     """Gather the ranks' compact tile buffers (all `mine.numel()` floats) on `dst`, where
@@ -84,7 +93,9 @@ class DistributedFrame:
         self.tile_floats, self.stride = partition_layout(til.n_tiles, til.tile_w, til.tile_h, nranks)
         w = self.r.world
         self.is_root = rank == 0
-        self.frames = [torch.zeros(w.height * w.width * 3, dtype=torch.float32, device=device)
+        # (a rehearsal renders its share as compact tiles into the frame buffers: whole tiles)
+        frame_floats = max(w.height * w.width * 3, compact_floats(til) if self.rehearsal else 0)
+        self.frames = [torch.zeros(frame_floats, dtype=torch.float32, device=device)
                        for _ in range(self.depth)] if self.is_root else [None] * self.depth
         # every context renders on ITS OWN stream (created by rt_init, one hardware queue each);
         # torch only wraps it, so that events and the collective's stream can be ordered
@@ -115,9 +126,8 @@ class DistributedFrame:
                 r.set_concurrency(div)
             return (self.depth, div)
         import time
-        w = self.renderers[0].world
-        scratch = [torch.zeros(w.height * w.width * 3 + 4096, dtype=torch.float32, device=self.device)
-                   for _ in range(self.depth)]
+        scratch = [torch.zeros(max(64, compact_floats(self.renderers[0].tiling())), dtype=torch.float32,
+                               device=self.device) for _ in range(self.depth)]
         candidates = [(1, 1)]
         for f in range(2, self.depth + 1):
             candidates += [(f, 1), (f, f - 1), (f, f)] if f > 2 else [(f, 1), (f, f)]

@@ -265,10 +265,13 @@ def test_many_lights_shadow_pool(rt, oracle, renderer, n_extra, name):
         assert np.allclose(g_rgb[fin], o_rgb[fin], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name,rpp,depth", [("bench1", 16, 6), ("bench5", 64, 6)])
-def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth):
+@pytest.mark.parametrize("name,rpp,depth,lens", [("bench1", 16, 6, None), ("bench5", 64, 6, None),
+                                                 ("bench4", 64, 6, 0.05), ("mesh:100000", 4, 6, None)])
+def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth, lens):
     """BASELINE.json's full size (1920x1080; configs[1] = bench1 at 16 spp, configs[3] = the
-    glossy scene at 64 spp), where the oracle needs minutes for a whole frame: size-independent
+    glossy scene AND the depth-of-field scene (bench4, lens 0.05, Main.hs:195-204) at 64 spp,
+    configs[2] = the station-style mesh of 100 000 triangles under bench6World's eight lights),
+    where the oracle needs minutes for a whole frame: size-independent
     properties instead -- the frame is bitwise reproducible, identical for an 8-way tile
     partition, the ray accounting closes (render maps colorPixel over W*H pixels x aa^2 samples,
     RayTracer.hs:18-23; one inShadow ray per light and shaded hit, :93-100, in the reference's
@@ -277,7 +280,8 @@ def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth):
     (ids bit-exact, 8-bit |delta| <= 1, PSNR >= 50 dB)."""
     import torch
     W, H = 1920, 1080
-    w = make_world(rt, name, W, H, rpp, depth=depth, view=(16, 9, 10))
+    w = make_world(rt, name, W, H, rpp, depth=depth, view=(16, 9, 10), lens=lens)
+    assert w.camera.lens == (lens or 0.0)
     grids = rt.generate_grids(77, W + 10, w.camera.aa)
     renderer.set_partition(0, 1)
     renderer.set_world(w)
@@ -311,12 +315,201 @@ def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth):
     assert rays == a_st.rays_total
     assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(-1, 3), a_rgb.view(np.uint32))
     # stripes against the oracle
-    n_rows = 2 if rpp > 16 else 4
+    n_rows = 2 if rpp > 16 else (4 if rpp > 4 else 8)
     for r0 in (0, H // 3, (2 * H) // 3 + 1, H - n_rows):
         o_rgb, o_ids, _ = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT, rows=(r0, r0 + n_rows))
         sl = slice(r0 * W, (r0 + n_rows) * W)
         assert int((a_ids[sl] != o_ids[sl]).sum()) == 0
         check_image(rt, a_rgb[sl], o_rgb[sl])
+
+
+def test_4k_animation_frames_properties(rt, oracle, renderer):
+    """BASELINE.json configs[4]: the orbit animation at 3840x2160 (bench.py workload c5).  Two
+    frames of the sequence, each: bitwise reproducible, ray accounting closed, an 8-way tile
+    partition assembles to the identical frame, and stripes of rows equal the oracle's (ids
+    bit-exact, 8-bit |delta| <= 1, PSNR >= 50 dB).  The two frames differ (the spheres moved)."""
+    import importlib
+    import torch
+    anim = importlib.import_module("ray-tracer_amd.animation")
+    d = anim.parse_scene_description(anim.ORBIT_DESCRIPTION)
+    W, H = 3840, 2160
+    cfg = rt.Config(image_width=W, image_height=H, anti_aliasing=4, reflection_depth=6)
+    grids = rt.generate_grids(31, W + 10, 2)
+    frames = []
+    for t in (0.0, 17.0):
+        w = d.world_at(t, cfg)
+        renderer.set_partition(0, 1)
+        renderer.set_world(w)
+        renderer.set_samples(grids)
+        a_rgb, a_ids, a_st = renderer.render(0, want_hit_ids=True)
+        b_rgb, _, b_st = renderer.render(0)
+        assert np.array_equal(a_rgb.view(np.uint32), b_rgb.view(np.uint32))
+        assert a_st.rays_primary == W * H * 4 and a_st.rays_total == b_st.rays_total
+        assert a_st.primary_hits == int((a_ids != rt.HIT_NONE).sum())
+        n = 8
+        til = renderer.tiling()
+        stride = ((til.n_tiles + n - 1) // n) * til.tile_w * til.tile_h * 3
+        gathered = torch.zeros(n * stride, dtype=torch.float32, device="cuda:0")
+        rays = 0
+        for r in range(n):
+            renderer.set_partition(r, n)
+            renderer.render_tiles_async(gathered.data_ptr() + r * stride * 4)
+            rays += renderer.collect().rays_total
+        out = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+        renderer.set_partition(0, n)
+        renderer.assemble_async(gathered.data_ptr(), n, stride, out.data_ptr())
+        renderer.collect()
+        renderer.set_partition(0, 1)
+        assert rays == a_st.rays_total
+        assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(-1, 3), a_rgb.view(np.uint32))
+        for r0 in (0, H // 2 - 40, H // 2 + 120, H - 4):
+            o_rgb, o_ids, _ = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT, rows=(r0, r0 + 4))
+            sl = slice(r0 * W, (r0 + 4) * W)
+            assert int((a_ids[sl] != o_ids[sl]).sum()) == 0
+            check_image(rt, a_rgb[sl], o_rgb[sl])
+        frames.append(a_rgb)
+    assert not np.array_equal(frames[0], frames[1])
+
+
+def test_obj_loaded_scene_matches_oracle(rt, oracle, renderer, tmp_path):
+    """Config 3's data path end to end: a station-style mesh written as .obj/.mtl in the HaObj
+    dialect, read back by parseObj/convertMesh/fromMesh (HaObj.hs:63, Convert.hs:15-78 restated
+    in rth_scene_load_obj), lit by bench6World's eight lights (Main.hs:237-246), sahBVH built,
+    rendered on the GPU and compared with the oracle on the same loaded scene: both traversal
+    policies, ids and ray counts identical, frames to the parity bar."""
+    import os
+    from test_obj_import import dump_obj
+    src = rt.Scene.builtin("mesh:3000")
+    path = os.path.join(tmp_path, "station.obj")
+    dump_obj(src, path)
+    scene = rt.Scene.from_obj(path)
+    assert scene.view.n_triangles == src.view.n_triangles > 2000 and scene.view.n_lights == 8
+    mats = {scene.view.triangles[i].material for i in range(scene.view.n_triangles)}
+    refr = [m for m in mats if scene.view.materials[m].refr_ix != 0]
+    refl = [m for m in mats if scene.view.materials[m].refl != 0]
+    assert refr and refl          # illum 4/6 (refractive) and illum 3 (reflective) groups are present
+    cfg = rt.default_config("mesh")       # bench6Config (Main.hs:225-235) moved with the mesh
+    cfg.image_width, cfg.image_height, cfg.anti_aliasing = 192, 108, 4
+    cfg.view_width, cfg.view_height, cfg.view_distance = 16, 9, 10
+    w = rt.config_to_world(cfg, scene)
+    for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT),
+                           (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
+        (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 13, gflags, oflags)
+        assert int((g_ids != o_ids).sum()) == 0
+        assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+               (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+        assert g_st.rays_refraction > 0 and g_st.rays_reflection > 0 and g_st.primary_hits > 192 * 108
+        check_image(rt, g_rgb, o_rgb)
+
+
+def test_leaving_the_medium_branch_and_infinite_weights(rt, oracle, renderer):
+    """getIndirectColor's `dn >= 0` branch (RayTracer.hs:140-145: refract against the flipped
+    normal with 1/nt, k = exp(-attenuation), total internal reflection -> c = 0) is unreachable
+    with well-formed objects (triangles are culled against the very normal that dn is formed
+    with; a sphere never reports its far root).  A sphere of NEGATIVE radius is a legal `Sphere`
+    whose getNormal (:76) points inward, so every hit on it takes that branch -- with glass
+    (k = 1), diamond (more TIR) and greenGlass (attenuation (99, 0, 99): k = (1/99, +inf, 1/99),
+    Materials.hs:88, hence inf and inf * 0 = NaN colours).  Ids and ray counts must be identical;
+    the 8-bit frame equal within 1 wherever the reference's value is defined (not NaN: writePPM's
+    `truncate NaN` is garbage, Main.hs:131) -- +inf prints 255 on both sides."""
+    names = ["glass", "diamond", "greenGlass"]
+    mats = [rt.material(m) for m in names] + [rt.material("whiteDull"), rt.material("redDull")]
+    sph = [rt.Sphere((f32 * 3)(-4 + 4 * i, 2.0, 0.0), -1.5, i, i) for i in range(3)]
+    tris = [rt.make_triangle((-40, 0, -40), (-40, 0, 40), (40, 0, 40), 3),
+            rt.make_triangle((-40, 0, -40), (40, 0, 40), (40, 0, -40), 3),
+            rt.make_triangle((-40, 0, -10), (40, 0, -10), (40, 40, -10), 4),
+            rt.make_triangle((-40, 0, -10), (40, 40, -10), (-40, 40, -10), 4)]
+    for k, t in enumerate(tris):
+        t.object_id = 3 + k
+    order = [0, 1, 2] + [rt.REF_TRIANGLE | k for k in range(4)]
+    lights = [rt.Light((f32 * 3)(0, 30, 10), (f32 * 3)(2, 0, 0), (f32 * 3)(0, 0, 2), (f32 * 3)(0.8, 0.8, 0.8))]
+    # noBVH (BoundingVolumeHierarchy.hs:130): one leaf whose box the floor and the wall span (a
+    # negative radius turns the sphere's own toBox inside out)
+    sc = rt.Scene.create(sph, tris, order, mats, lights, bvh="none")
+    cfg = rt.Config(image_width=96, image_height=64, view_width=12, view_height=8, view_distance=10,
+                    reflection_depth=6, anti_aliasing=4, eye=(0.0, 3.0, 14.0), look_at=(0.0, 2.0, 0.0))
+    w = rt.config_to_world(cfg, sc)
+    for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT),
+                           (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
+        (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 5, gflags, oflags)
+        assert o_st.exit_branch > 1000 and o_st.tir > 500 and o_st.nonfinite_samples > 100
+        assert int((g_ids != o_ids).sum()) == 0
+        assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+               (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+        defined = ~np.isnan(o_rgb)
+        assert np.isinf(o_rgb).any() and (~defined).any()
+        g8, o8 = rt.quantize(g_rgb), rt.quantize(o_rgb)
+        d = np.abs(g8.astype(np.int32) - o8.astype(np.int32))[defined]
+        assert d.max() <= 1
+        assert (g8[np.isinf(o_rgb)] == 255).all()
+        fin = np.isfinite(o_rgb)
+        assert np.allclose(g_rgb[fin], o_rgb[fin], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", ["schlick_head_on_sphere", "schlick_60_degrees_pane",
+                                  "total_internal_reflection", "leaving_the_medium_beer"])
+@pytest.mark.parametrize("flags", [0, 6])   # default policy; NO_PRUNE | TRACE_ZERO_WEIGHT
+def test_indirect_colour_by_hand_on_the_gpu(rt, renderer, case, flags):
+    """The hand-derived getIndirectColor answers of tests/kat_scenes.py (Schlick R at normal and
+    60-degree incidence with both children, total internal reflection, Beer's law on leaving the
+    medium), checked against the HIP path DIRECTLY -- a 1x1 render whose only ray is the KAT ray --
+    not through the oracle."""
+    import kat_scenes
+    sc, cfg, expected = kat_scenes.CASES[case](rt)
+    w = rt.config_to_world(cfg, sc)
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(kat_scenes.CENTRE_SAMPLE)
+    rgb, ids, st = renderer.render(flags, want_hit_ids=True)
+    assert np.allclose(rgb[0], expected, rtol=2e-5, atol=1e-7), (rgb[0], expected)
+    assert ids[0, 0] == 0 and st.rays_primary == 1
+    assert st.rays_refraction == (0 if case == "total_internal_reflection" else 1)
+
+
+def test_compact_tile_buffer_is_whole_tiles(rt, renderer):
+    """rt_render_tiles_async writes n_local_tiles WHOLE tiles: with one rank and image sides that
+    are not multiples of the tile sides that is more than W*H*3 floats (800x600 at 1 spp: 19 tile
+    rows of 32 pixels = 608 rows).  Buffers sized by distributed.compact_floats hold it exactly:
+    guard words behind them stay untouched, and the start-up tuner / share rehearsal of
+    DistributedFrame (which render through the same call) size their buffers with it."""
+    import importlib
+    import torch
+    rtd = importlib.import_module("ray-tracer_amd.distributed")
+    W, H = 800, 600
+    w = make_world(rt, "bench1", W, H, 1)
+    grids = rt.generate_grids(3, W + 10, 1)
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    til = renderer.tiling()
+    n = rtd.compact_floats(til)
+    assert (til.tile_w, til.tile_h, til.tiles_y) == (32, 32, 19) and n == 25 * 19 * 32 * 32 * 3 > W * H * 3
+    guard = 1 << 16
+    buf = torch.full((n + guard,), -7.25, dtype=torch.float32, device="cuda:0")
+    renderer.render_tiles_async(buf.data_ptr())
+    renderer.collect()
+    h = buf.cpu().numpy()
+    assert (h[n:] == -7.25).all()                    # nothing behind the last tile
+    assert (h[W * H * 3:n] != -7.25).any()           # ... and the last tile row lies beyond W*H*3
+    full, _, _ = renderer.render(0)
+
+    def make_renderer():
+        r = rt.Renderer(0)
+        r.set_world(w)
+        r.set_samples(grids)
+        return r
+    dev = torch.device("cuda", 0)
+    for kw in ({}, {"rehearse_share": (0, 1)}):
+        df = rtd.DistributedFrame(make_renderer, 0, 1, dev, in_flight=2, **kw)
+        try:
+            assert df.frames[0].numel() >= (n if kw else W * H * 3)
+            for _ in range(3):
+                df.submit()
+            df.finish()
+            if not kw:
+                assert np.array_equal(df.frame.cpu().numpy().reshape(-1, 3), full)
+        finally:
+            df.close()
 
 
 def test_rank_without_tiles_renders_nothing(rt, renderer):
@@ -417,6 +610,62 @@ def test_boundary_reports_misuse_as_errors(rt):
         r.set_samples(rt.generate_grids(1, 74, 2))                  # now consistent: the context still works
         rgb, _, st = r.render(0)
         assert st.rays_primary == 64 * 48 * 4 and np.isfinite(rgb).all()
+    finally:
+        r.close()
+
+
+def _chain_scene(rt, depth, n_lights):
+    """A BVH that is one long chain: inner node i = (leaf {triangle i}, inner node i+1), `depth`
+    levels deep.  Triangle k lies in z = -k over x in [k, k+1], facing +z."""
+    mats = [rt.material("whiteDull"), rt.material("redDull")]
+    tris = []
+    for k in range(depth):
+        t = rt.make_triangle((k, -1, -k), (k + 1, -1, -k), (k, 2, -k), k & 1)
+        t.object_id = k
+        tris.append(t)
+    assert list(tris[0].n) == [0.0, 0.0, 1.0]
+    nodes = []
+    for k in range(depth - 1):                       # inner node 2k, leaf 2k+1
+        nodes.append(rt.BvhNode(k, depth, -1, 2, -(depth - 1), -k, 2 * k + 1, 2 * k + 2))
+        nodes.append(rt.BvhNode(k, k + 1, -1, 2, -k, -k, -1 - k, 1))
+    k = depth - 1
+    nodes.append(rt.BvhNode(k, k + 1, -1, 2, -k, -k, -1 - k, 1))   # the last leaf closes the chain
+    refs = (C.c_uint32 * depth)(*[rt.REF_TRIANGLE | k for k in range(depth)])
+    lights = [rt.Light((f32 * 3)(depth / 2 + 7 * i, 3 * i, 40), (f32 * 3)(0, 0, 0), (f32 * 3)(0, 0, 0),
+                       (f32 * 3)(0.4, 0.4, 0.4)) for i in range(n_lights)]
+    arr = lambda T, xs: (T * max(1, len(xs)))(*xs)
+    view = rt.SceneView(arr(rt.BvhNode, nodes), len(nodes), refs, depth, arr(rt.Sphere, []), 0,
+                        arr(rt.Triangle, tris), depth, arr(rt.Material, mats), 2, arr(rt.Light, lights), n_lights)
+    view._keep = (nodes, tris, mats, lights)
+    return view
+
+
+@pytest.mark.parametrize("n_lights", [1, 3])
+def test_deep_chain_bvh_up_to_the_stack_limit(rt, oracle, renderer, n_lights):
+    """rt_upload_scene accepts trees up to 64 levels and rejects deeper ones with RT_ERR_LIMIT; a
+    64-level tree must then also RENDER: its per-lane traversal stacks need more than the 64 KB of
+    dynamic LDS a kernel gets by default (66 KB with one light, 74 KB with the shadow-ray pool of
+    several lights), which every kernel of the path (probe and render) has to ask for."""
+    from types import SimpleNamespace
+    cfg = rt.Config(image_width=160, image_height=6, view_width=64, view_height=2, view_distance=30,
+                    reflection_depth=2, anti_aliasing=1, eye=(32.0, 0.4, 30.0), look_at=(32.0, 0.4, 0.0))
+    cam = rt.config_to_world(cfg, rt.Scene.builtin("kat_tris")).camera
+    grids = rt.generate_grids(4, 170, 1)
+    r = rt.Renderer(0)
+    try:
+        deep = SimpleNamespace(scene=SimpleNamespace(view=_chain_scene(rt, 65, n_lights)), camera=cam)
+        with pytest.raises(rt.RtError, match="depth 65 exceeds"):
+            r.set_world(deep)
+        v = _chain_scene(rt, 64, n_lights)
+        w = SimpleNamespace(scene=SimpleNamespace(view=v), camera=cam, width=160, height=6, spp=1)
+        r.set_world(w)
+        r.set_samples(grids)
+        for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT), (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
+            g_rgb, g_ids, g_st = r.render(gflags, want_hit_ids=True)
+            o_rgb, o_ids, o_st = oracle.render(w, grids, oflags)
+            assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
+            assert len(np.unique(g_ids)) > 40          # most of the chain's triangles are seen
+            check_image(rt, g_rgb, o_rgb)
     finally:
         r.close()
 

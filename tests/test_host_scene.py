@@ -222,3 +222,64 @@ def test_fastdiv_constants_are_exact(tmp_path):
                     os.path.join(root, "tools", "check_fastdiv.cpp"), "-o", exe], check=True)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "fastdiv ok" in p.stdout, p.stdout[-500:]
+
+
+def _x_spheres(rt, xs):
+    import ctypes as C
+    f32 = C.c_float
+    mats = [rt.material("whiteDull")]
+    sph = [rt.Sphere((f32 * 3)(x, 0, 0), 1.0, 0, i) for i, x in enumerate(xs)]
+    return rt.Scene.create(sph, [], list(range(len(xs))), mats, [], bvh="sah")
+
+
+def _tree(scene):
+    """(nested tuple of leaf object lists, root box) from the flattened BVH."""
+    nodes, refs = scene.nodes(), scene.leaf_refs()
+
+    def go(i):
+        n = nodes[i]
+        if n["left"] < 0:
+            first = -1 - int(n["left"])
+            return [int(r) for r in refs[first:first + int(n["right"])]]
+        return (go(int(n["left"])), go(int(n["right"])))
+    return go(0), [float(x) for x in nodes[0]["box"]]
+
+
+def test_sah_split_by_hand_with_the_surface_area_quirk(rt):
+    """sahBVH / bestSplit / sahCost / surfaceArea (BoundingVolumeHierarchy.hs:34-94) followed BY
+    HAND on four unit spheres on the x axis at x = -12, -11, -5, 2 (boxes [-13,-11], [-12,-10],
+    [-6,-4], [1,3] in x, [-1,1] in y and z).  surfaceArea uses `w = abs r - l` (:90), i.e.
+    |r| - l, NOT |r - l|: for a box left of the origin that is -(r + l).  h = d = |1| - (-1) = 2.
+
+      root: box [-13,3]: w = 16, area = 2 (32 + 32 + 4) = 136; leafCost = 4
+        i=1: left {0}: w = |-11| + 13 = 24 -> 200;  right {1,2,3}: [-12,3] w = 15 -> 128
+             cost = 0.6 + (200*1 + 128*3)/136 = 4.894
+        i=2: left {0,1}: [-13,-10] w = 10 + 13 = 23 -> 192;  right {2,3}: [-6,3] w = 9 -> 80
+             cost = 0.6 + (192*2 + 80*2)/136 = 4.600
+        i=3: left {0,1,2}: [-13,-4] w = 4 + 13 = 17 -> 144;  right {3}: [1,3] w = 2 -> 24
+             cost = 0.6 + (144*3 + 24*1)/136 = 3.953   <- minimum, < 4: Node, split 3 | 1
+        (i = 0 and i = 4: area(EmptyBox) = inf times count 0 = NaN, filtered, :68-70.  The y and
+         z axes see four equal midpoints: the stable sortOn keeps the order, the costs are the
+         same, and minimumBy keeps the FIRST minimum, the x axis, :45-46.)
+        With the true area |r - l| the costs would be 3.60, 2.25, 2.54: split 2 | 2 -- the quirk
+        decides this tree.
+      left {0,1,2}: box [-13,-4] area 144, leafCost = 3
+        i=1: {0} 200, {1,2}: [-12,-4] w = 16 -> 136: cost = 0.6 + (200 + 272)/144 = 3.878
+        i=2: {0,1} 192, {2}: [-6,-4] w = 10 -> 88:   cost = 0.6 + (384 + 88)/144 = 3.878
+        bestCost 3.878 > 3 -> Leaf [0,1,2]  (:39)
+      right {3}: length < 3 -> Leaf [3]
+
+    Mirrored to the right of the origin (x = 2, 3, 9, 16) the quirk is inactive (|r| = r) and the
+    true-area split 2 | 2 is taken: i=2: {0,1}: [1,4] w = 3 -> 32; {2,3}: [8,17] w = 9 -> 80;
+    cost = 0.6 + (64 + 160)/136 = 2.247 (i=1: 0.6 + (24 + 3*128)/136 = 3.6; i=3: 0.6 + (3*80 + 24)/136
+    = 2.541); both halves have fewer than 3 objects -> leaves."""
+    tree, box = _tree(_x_spheres(rt, [-12, -11, -5, 2]))
+    assert tree == ([0, 1, 2], [3])
+    assert box == [-13.0, 3.0, -1.0, 1.0, -1.0, 1.0]
+    tree, box = _tree(_x_spheres(rt, [2, 3, 9, 16]))
+    assert tree == ([0, 1], [2, 3])
+    assert box == [1.0, 17.0, -1.0, 1.0, -1.0, 1.0]
+    # order of the input list does not matter for the split, but the leaf keeps the SORTED order
+    # (splitAt on the list re-sorted along the best axis, :47)
+    tree, _ = _tree(_x_spheres(rt, [2, -5, -12, -11]))
+    assert tree == ([2, 3, 1], [0])

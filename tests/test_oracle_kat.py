@@ -288,3 +288,24 @@ def test_default_ray_policy_never_changes_a_finite_pixel(rt, oracle):
         assert b_st.rays_primary == a_st.rays_primary
         assert b_st.rays_shadow <= a_st.rays_shadow and b_st.rays_reflection <= a_st.rays_reflection
         assert b_st.rays_total < a_st.rays_total
+
+
+# --- getIndirectColor (RayTracer.hs:109-156): Schlick, TIR, Beer's law, both children ---
+@pytest.mark.parametrize("case", ["schlick_head_on_sphere", "schlick_60_degrees_pane",
+                                  "total_internal_reflection", "leaving_the_medium_beer"])
+def test_indirect_colour_by_hand(rt, oracle, case):
+    """tests/kat_scenes.py derives each colour by hand from the reference source; the oracle must
+    reproduce it (whole-frame render of the 1x1 image whose only ray is the KAT ray)."""
+    import kat_scenes
+    sc, cfg, expected = kat_scenes.CASES[case](rt)
+    w = rt.config_to_world(cfg, sc)
+    rgb, ids, st = oracle.render(w, kat_scenes.CENTRE_SAMPLE, 0)
+    assert np.allclose(rgb[0], expected, rtol=2e-5, atol=1e-7), (rgb[0], expected)
+    assert ids[0, 0] == 0                                    # the refractive surface is object 0
+    if case == "total_internal_reflection":
+        assert st.rays_refraction == 0 and st.tir == 0       # TIR on ENTERING (nt < 1): not the exit branch
+    else:
+        assert st.rays_refraction == 1
+    # (the walls' own zero-weight reflection rays come back to the sphere, so the branch count is
+    #  3 with the inside-out sphere: the KAT ray's hit and two grandchildren)
+    assert (st.exit_branch >= 1) == (case == "leaving_the_medium_beer")
