@@ -281,7 +281,7 @@ def test_full_size_frame_properties(rt, oracle, renderer, name, rpp, depth, lens
     import torch
     W, H = 1920, 1080
     w = make_world(rt, name, W, H, rpp, depth=depth, view=(16, 9, 10), lens=lens)
-    assert w.camera.lens == (lens or 0.0)
+    assert w.camera.lens == pytest.approx(lens or 0.0)
     grids = rt.generate_grids(77, W + 10, w.camera.aa)
     renderer.set_partition(0, 1)
     renderer.set_world(w)
