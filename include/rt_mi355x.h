@@ -18,7 +18,11 @@
  * negative rt_status; nothing throws or aborts across the boundary; the library
  * copies host inputs on upload and never keeps a host pointer; all outputs are
  * caller-allocated.  A context is bound to one GPU, is not thread-safe, and all
- * calls are synchronous unless the name ends in _async.
+ * calls are synchronous unless the name ends in _async.  A context has ONE frame in
+ * flight (one set of work buffers): frames enqueued on the same stream queue up behind
+ * each other; a frame enqueued on another stream than the context's previous one first
+ * waits (on the host) for that one -- use one context per stream to overlap frames.  A
+ * caller's stream must stay alive until the context's next call.
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
@@ -208,6 +212,22 @@ int rt_render(rt_ctx *ctx, uint32_t flags, float *rgb_out, uint32_t *primary_hit
  * d_rgb as rgb_out above.  With nranks > 1 use rt_render_tiles_async instead. */
 int rt_render_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_primary_hit_ids,
                     void *hip_stream);
+
+/* rt_render_async for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  NO counterpart in the
+ * reference.  Same inputs, outputs and results (bit for bit) as rt_render_async, but every
+ * per-frame work buffer (pixel sums, ticket counters, packet order, per-wave ray queues,
+ * statistics) lives in a static device array of the library, at most 32 MiB per GPU, held
+ * from library load to process end, instead of the context's hipMalloc'ed buffers: the call
+ * performs no hipMalloc / hipFree, nor any other allocating routine.  Limits (RT_ERR_LIMIT with
+ * a message beyond them): img_w x img_h rounded up to whole tiles <= 262 144 pixels (e.g.
+ * 640x360, 512x512), max_depth <= 6, whole frames only (partition (0,1)); the launch uses at
+ * most 512 persistent waves, so it is slower than rt_render_async on large frames.  The
+ * scene, camera and samples are set up beforehand with the usual calls (which do allocate).
+ * ALL calls on one GPU -- from any context -- share that GPU's array: calls that overlap on a
+ * GPU race; serialise them (one stream, or events).  rt_collect works as usual afterwards. */
+int rt_render_static_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_primary_hit_ids,
+                           void *hip_stream);
 
 /* Partitioned form: writes this rank's tiles compactly,
  * d_tiles[n_local_tiles][tile_h][tile_w][3] floats (local tile l is global tile

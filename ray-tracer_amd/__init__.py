@@ -114,7 +114,7 @@ DEVICE_SYMBOLS = [
     "rt_init", "rt_shutdown", "rt_upload_scene", "rt_set_camera", "rt_set_samples",
     "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
-    "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing",
+    "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing", "rt_render_static_async",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -219,6 +219,7 @@ def device_lib() -> C.CDLL:
         L.rt_render.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(u32), C.POINTER(Stats)]
         L.rt_render_async.argtypes = [vp, u32, vp, vp, vp]
         L.rt_render_tiles_async.argtypes = [vp, u32, vp, vp]
+        L.rt_render_static_async.argtypes = [vp, u32, vp, vp, vp]
         L.rt_assemble_async.argtypes = [vp, vp, i32, C.c_size_t, vp, vp]
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
         L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
@@ -499,6 +500,12 @@ class Renderer:
     def render_async(self, d_rgb: int, d_hit_ids: int = 0, flags: int = 0, stream: int = 0) -> None:
         self._check(self.lib.rt_render_async(self._h, flags, d_rgb, d_hit_ids or None,
                                              stream or None), "rt_render_async")
+
+    def render_static_async(self, d_rgb: int, d_hit_ids: int = 0, flags: int = 0, stream: int = 0) -> None:
+        """rt_render_static_async: rt_render_async on the library's static work memory (no
+        allocation; at most 262 144 pixels, depth 6; calls on one GPU must not overlap)."""
+        self._check(self.lib.rt_render_static_async(self._h, flags, d_rgb, d_hit_ids or None,
+                                                    stream or None), "rt_render_static_async")
 
     def render_tiles_async(self, d_tiles: int, flags: int = 0, stream: int = 0) -> None:
         self._check(self.lib.rt_render_tiles_async(self._h, flags, d_tiles, stream or None),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct rt_ctx {
   bool acc_clean = false;  // every pixel sum of d_acc is zero (left so by resolve_kernel)
   unsigned *d_tile_counter = nullptr;
   unsigned long long *d_stats = nullptr;
+  unsigned long long *last_stats = nullptr;  // statistics block of the newest launch (own or static work memory)
   long long *d_acc = nullptr;
   size_t acc_samples = 0;
   unsigned char *d_pclass = nullptr;
@@ -75,7 +77,67 @@ struct rt_ctx {
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
 };
 
+// ---- the library's static work memory (rt_render_static_async) --------------------------
+// One array per GPU the code object is loaded on, held until the process ends.  In HOST code
+// the array's name is only a stand-in (passing it to a kernel compiles and then faults on the
+// GPU): its device address is looked up once per device in rt_init (hipGetSymbolAddress) and
+// only that pointer is used below.  Layout (all offsets multiples of 256 B):
+//   stats | ticket counters | block histograms | packet classes | packet order | pixel sums | ray queues
+constexpr size_t ST_MAX_PIXELS = 1u << 18;   // local pixels incl. tile padding (e.g. 640x360, 512x512)
+constexpr int ST_MAX_WAVES = 512;            // persistent waves of the launch (the normal path uses up to 5120)
+constexpr int ST_MAX_DEPTH = 6;              // wMaxDepth (every shipped config uses 6)
+constexpr size_t ST_STATS_BYTES = (16 + 4 * 16384 + 32) * sizeof(unsigned long long);
+constexpr size_t ST_COUNTER_BYTES = PACKET_SHARDS * 32 * sizeof(unsigned);
+constexpr size_t ST_HIST_BYTES = (1024 * 4 + 64) * sizeof(unsigned);
+constexpr size_t ST_ORDER_ENTRIES = ST_MAX_PIXELS;  // one entry per packet, or per pixel of a refractive packet
+constexpr size_t ST_QUEUE_FLOATS = (size_t)ST_MAX_WAVES * (((size_t)(ST_MAX_DEPTH - 1) * QFIELDS * QCAP + 63) & ~(size_t)63);
+constexpr size_t st_align(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t ST_OFF_STATS = 0;
+constexpr size_t ST_OFF_COUNTER = ST_OFF_STATS + st_align(ST_STATS_BYTES);
+constexpr size_t ST_OFF_HIST = ST_OFF_COUNTER + st_align(ST_COUNTER_BYTES);
+constexpr size_t ST_OFF_PCLASS = ST_OFF_HIST + st_align(ST_HIST_BYTES);
+constexpr size_t ST_OFF_ORDER = ST_OFF_PCLASS + st_align(ST_ORDER_ENTRIES);
+constexpr size_t ST_OFF_ACC = ST_OFF_ORDER + st_align(ST_ORDER_ENTRIES * sizeof(int));
+constexpr size_t ST_OFF_QUEUES = ST_OFF_ACC + st_align(ST_MAX_PIXELS * 3 * sizeof(long long));
+constexpr size_t ST_BYTES = ST_OFF_QUEUES + st_align(ST_QUEUE_FLOATS * sizeof(float));
+static_assert(ST_BYTES <= 32u * 1024 * 1024, "static work memory is documented as at most 32 MiB per GPU");
+
+static __device__ __align__(256) unsigned char scratch[ST_BYTES];
+
 namespace {
+
+constexpr int ST_MAX_DEVICES = 64;
+unsigned char *g_static_ptr[ST_MAX_DEVICES] = {nullptr};  // device address of `scratch` on each GPU
+std::mutex g_static_mutex;
+
+// once per device, with that device current (rt_init)
+hipError_t lookup_static_scratch(int device) {
+  if (device < 0 || device >= ST_MAX_DEVICES) return hipSuccess;  // such a device simply has no static path
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (g_static_ptr[device]) return hipSuccess;
+  void *p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return e;
+  g_static_ptr[device] = static_cast<unsigned char *>(p);
+  return hipSuccess;
+}
+
+// The per-frame work memory of one launch: the context's own allocations (prepare) or the
+// carved-up static array.
+struct WorkMem {
+  float *queues = nullptr;
+  int queue_waves = 0;
+  long long *acc = nullptr;
+  size_t acc_pixels = 0;
+  unsigned *tile_counter = nullptr;
+  unsigned long long *stats = nullptr;
+  unsigned char *pclass = nullptr;
+  unsigned *block_hist = nullptr;
+  int *order = nullptr;
+  size_t order_cap = 0;
+  bool acc_known_clean = false;  // every pixel sum is zero (left so by the previous resolve_kernel)
+  int max_waves = 1 << 30;       // cap of the launch's persistent waves
+};
 
 int fail(rt_ctx *c, int code, const char *fmt, ...) {
   if (c) {
@@ -274,21 +336,36 @@ __global__ void quantize_kernel(const float *__restrict__ in, uint8_t *__restric
   }
 }
 
-int prepare(rt_ctx *c, uint32_t flags) {
+// State checks and the launch geometry that follows from camera / samples / partition.  No
+// device call, no allocation.
+int validate(rt_ctx *c) {
   if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_upload_scene has not been called");
   if (!c->have_cam) return fail(c, RT_ERR_STATE, "rt_set_camera has not been called");
   if (!c->have_samples) return fail(c, RT_ERR_STATE, "rt_set_samples has not been called");
   if (c->spp != c->cam.aa * c->cam.aa)
     return fail(c, RT_ERR_INVALID, "samples have spp=%d but camera aa=%d needs %d", c->spp, c->cam.aa,
                 c->cam.aa * c->cam.aa);
-  (void)flags;
-  if (c->prepared) return RT_OK;
   compute_tiling(c);
   c->stack_depth = std::max(4, (c->tree_depth + 3) & ~3);
-  int tile_samples = c->tiling.tile_w * c->tiling.tile_h * c->spp;
   c->scratch_stride = (scratch_floats_per_wave(c->cam.max_depth) + 63) & ~63ull;
-  (void)tile_samples;
-  size_t need_samples = (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h;  // pixels
+  const int ppp = std::max(1, 64 / c->spp);
+  const size_t n_packets = (size_t)c->tiling.n_local_tiles * ((size_t)(c->tiling.tile_w * c->tiling.tile_h + ppp - 1) / ppp);
+  if (n_packets >= (1u << 24)) return fail(c, RT_ERR_LIMIT, "too many packets (%zu)", n_packets);
+  return RT_OK;
+}
+size_t local_pixels(const rt_ctx *c) { return (size_t)c->tiling.n_local_tiles * c->tiling.tile_w * c->tiling.tile_h; }
+size_t order_entries(const rt_ctx *c) {
+  const int ppp = std::max(1, 64 / c->spp);
+  // a refractive packet may expand to one entry per pixel
+  return (size_t)c->tiling.n_local_tiles * ((size_t)(c->tiling.tile_w * c->tiling.tile_h + ppp - 1) / ppp) * (size_t)ppp;
+}
+
+// The context's own work memory (allocated on first use and whenever it has to grow).
+int prepare(rt_ctx *c) {
+  int rc = validate(c);
+  if (rc) return rc;
+  if (c->prepared) return RT_OK;
+  size_t need_samples = local_pixels(c);
   if (need_samples > c->acc_samples) {
     if (c->d_acc) (void)hipFree(c->d_acc);
     c->d_acc = nullptr;
@@ -308,18 +385,14 @@ int prepare(rt_ctx *c, uint32_t flags) {
   }
   c->scratch_waves = waves;
   {
-    int ppp = std::max(1, 64 / c->spp);
-    size_t n_packets = (size_t)c->tiling.n_local_tiles *
-                       ((size_t)(c->tiling.tile_w * c->tiling.tile_h + ppp - 1) / ppp);
-    if (n_packets >= (1u << 24)) return fail(c, RT_ERR_LIMIT, "too many packets (%zu)", n_packets);
-    n_packets *= (size_t)ppp;  // order entries: a refractive packet expands to one entry per pixel
-    if (n_packets > c->order_cap || !c->d_order) {
+    size_t n_entries = order_entries(c);
+    if (n_entries > c->order_cap || !c->d_order) {
       if (c->d_order) (void)hipFree(c->d_order);
       if (c->d_pclass) (void)hipFree(c->d_pclass);
       c->d_order = nullptr;
       c->d_pclass = nullptr;
       c->order_cap = 0;
-      size_t cap = std::max<size_t>(n_packets, 256);
+      size_t cap = std::max<size_t>(n_entries, 256);
       HIP_TRY(c, hipMalloc((void **)&c->d_order, cap * sizeof(int)));
       HIP_TRY(c, hipMalloc((void **)&c->d_pclass, cap));
       c->order_cap = cap;
@@ -330,9 +403,25 @@ int prepare(rt_ctx *c, uint32_t flags) {
   return RT_OK;
 }
 
-int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids, hipStream_t s) {
-  int rc = prepare(c, flags);
-  if (rc) return rc;
+WorkMem own_work_memory(const rt_ctx *c) {
+  WorkMem m;
+  m.queues = c->d_scratch;
+  m.queue_waves = c->scratch_waves;
+  m.acc = c->d_acc;
+  m.acc_pixels = c->acc_samples;
+  m.tile_counter = c->d_tile_counter;
+  m.stats = c->d_stats;
+  m.pclass = c->d_pclass;
+  m.block_hist = c->d_block_hist;
+  m.order = c->d_order;
+  m.order_cap = c->order_cap;
+  m.acc_known_clean = c->acc_clean;
+  return m;
+}
+
+// Enqueue one frame (probe, order, render, resolve kernels) on `s` with the work memory `m`.
+// The caller has validated the context (prepare / validate) and sized `m` for it.
+int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids, hipStream_t s, const WorkMem &m) {
   HIP_TRY(c, hipSetDevice(c->device));
   // A context owns ONE set of per-frame work buffers (pixel sums, ticket counters, packet order,
   // ray queues): it has one frame in flight.  Frames on the same stream are ordered by the stream;
@@ -379,9 +468,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.compact = compact;
   p.rgb = d_out;
   p.hit_ids = d_ids;
-  p.scratch = c->d_scratch;
+  p.scratch = m.queues;
   p.scratch_stride = c->scratch_stride;
-  p.acc = c->d_acc;
+  p.acc = m.acc;
   p.px_per_packet = std::max(1, 64 / c->spp);
   p.chunks_per_packet = (c->spp + 63) / 64;
   p.groups_per_tile = (c->tiling.tile_w * c->tiling.tile_h + p.px_per_packet - 1) / p.px_per_packet;
@@ -391,8 +480,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.fd_spp = make_fastdiv((unsigned)p.spp);
   p.fd_tile_w = make_fastdiv((unsigned)p.tile_w);
   p.fd_n_grids = make_fastdiv((unsigned)p.n_grids);
-  p.tile_counter = c->d_tile_counter;
-  p.stats = c->d_stats;
+  p.tile_counter = m.tile_counter;
+  p.stats = m.stats;
   p.stack_depth = c->stack_depth;
   p.trace_zero_weight = (flags & RT_FLAG_TRACE_ZERO_WEIGHT) ? 1 : 0;
 
@@ -439,8 +528,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   per_cu = std::min(per_cu, 8);
   int want = (p.n_packets + wpb - 1) / wpb;
   cfg.grid = std::max(1, std::min(c->n_cus * per_cu / std::max(1, c->grid_div), want));
-  if (cfg.grid * wpb > c->scratch_waves)
-    return fail(c, RT_ERR_LIMIT, "grid exceeds the scratch allocation");
+  cfg.grid = std::max(1, std::min(cfg.grid, m.max_waves / wpb));
+  if (cfg.grid * wpb > m.queue_waves)
+    return fail(c, RT_ERR_LIMIT, "grid exceeds the ray-queue memory");
 
   // Refractive packets (a binary ray tree per sample) are handed out pixel by pixel when the
   // rank has few packets per wave: the frame then ends on quarter-size work items.
@@ -461,29 +551,40 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
   p.probe_blocks = std::max(1, (p.n_packets + p.probe_span - 1) / p.probe_span);
-  p.pclass = c->d_pclass;
-  p.block_hist = c->d_block_hist;
-  p.class_totals = c->d_block_hist + 1024 * 4;
-  p.order = c->d_order;
+  p.pclass = m.pclass;
+  p.block_hist = m.block_hist;
+  p.class_totals = m.block_hist + 1024 * 4;
+  p.order = m.order;
   // Ticket counters and statistics are cleared by order_kernel (which precedes render_kernel),
   // the pixel sums by the previous frame's resolve_kernel after it has read them; explicit
   // clears only where those have not run: no packets, or sums not known to be zero (new or
   // resized buffer, a frame that failed half way).
   if (p.n_packets == 0) {
-    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
+    HIP_TRY(c, hipMemsetAsync(m.tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
+    HIP_TRY(c, hipMemsetAsync(m.stats, 0, 16 * sizeof(unsigned long long), s));
+    HIP_TRY(c, hipMemsetAsync(m.stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
   }
-  if (!c->acc_clean)
-    HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, c->acc_samples * 3 * sizeof(long long), s));
-  c->acc_clean = false;
+  if (!m.acc_known_clean && m.acc_pixels)
+    HIP_TRY(c, hipMemsetAsync(m.acc, 0, m.acc_pixels * 3 * sizeof(long long), s));
+  c->last_stats = m.stats;
   if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
   HIP_TRY(c, hipGetLastError());
-  c->acc_clean = true;  // resolve_kernel is enqueued: it leaves every sum it reads at zero
   if (c->timing) HIP_TRY(c, hipEventRecord(c->ev1, s));
   c->timed = c->timing;
+  return RT_OK;
+}
+
+// A frame on the context's own work memory (every entry point but the static one).
+int launch_own(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids, hipStream_t s) {
+  int rc = prepare(c);
+  if (rc) return rc;
+  const WorkMem m = own_work_memory(c);
+  c->acc_clean = false;  // until resolve_kernel is known to be enqueued
+  rc = launch(c, flags, d_out, compact, d_ids, s, m);
+  if (rc) return rc;
+  c->acc_clean = true;   // resolve_kernel is enqueued: it leaves every sum it reads at zero
   return RT_OK;
 }
 
@@ -492,7 +593,7 @@ int collect(rt_ctx *c, hipStream_t s, rt_stats *st) {
   if (!st) return RT_OK;
   std::memset(st, 0, sizeof *st);
   unsigned long long h[12];
-  HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(h, c->last_stats ? c->last_stats : c->d_stats, sizeof h, hipMemcpyDeviceToHost));
   st->rays_primary = h[0];
   st->rays_shadow = h[1];
   st->rays_reflection = h[2];
@@ -535,6 +636,12 @@ int rt_init(int device, rt_ctx **out) {
     return RT_ERR_DEVICE;
   }
   c->n_cus = prop.multiProcessorCount;
+  // device address of the library's static work memory on THIS GPU (rt_render_static_async)
+  if (hipError_t e = lookup_static_scratch(device); e != hipSuccess) {
+    std::fprintf(stderr, "rt_init: hipGetSymbolAddress(scratch) failed on device %d: %s\n", device, hipGetErrorString(e));
+    delete c;
+    return RT_ERR_DEVICE;
+  }
   if (const char *e = std::getenv("RT_SPLIT_REFRACTIVE")) c->split_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_LDS_SCENE")) c->lds_scene_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_GRID_DIV")) c->grid_div = std::max(1, std::atoi(e));
@@ -678,13 +785,48 @@ int rt_get_tiling(rt_ctx *c, rt_tiling *out) {
 int rt_render_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_ids, void *stream) {
   if (!c || !d_rgb) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  return launch(c, flags, d_rgb, 0, d_ids, s);
+  return launch_own(c, flags, d_rgb, 0, d_ids, s);
 }
 
 int rt_render_tiles_async(rt_ctx *c, uint32_t flags, float *d_tiles, void *stream) {
   if (!c || !d_tiles) return RT_ERR_INVALID;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  return launch(c, flags, d_tiles, 1, nullptr, s);
+  return launch_own(c, flags, d_tiles, 1, nullptr, s);
+}
+
+int rt_render_static_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_ids, void *stream) {
+  if (!c || !d_rgb) return RT_ERR_INVALID;
+  int rc = validate(c);  // state checks and launch geometry only: no allocation
+  if (rc) return rc;
+  if (c->rank != 0 || c->nranks != 1)
+    return fail(c, RT_ERR_STATE, "rt_render_static_async renders whole frames: reset the partition to (0, 1)");
+  unsigned char *base = (c->device >= 0 && c->device < ST_MAX_DEVICES) ? g_static_ptr[c->device] : nullptr;
+  if (!base) return fail(c, RT_ERR_DEVICE, "no static work memory on device %d", c->device);
+  if (local_pixels(c) > ST_MAX_PIXELS)
+    return fail(c, RT_ERR_LIMIT, "rt_render_static_async: %zu pixels (image %dx%d rounded up to whole %dx%d tiles) exceed "
+                "the static work memory's limit of %zu", local_pixels(c), c->cam.img_w, c->cam.img_h, c->tiling.tile_w,
+                c->tiling.tile_h, ST_MAX_PIXELS);
+  if (c->cam.max_depth > ST_MAX_DEPTH)
+    return fail(c, RT_ERR_LIMIT, "rt_render_static_async: max_depth %d exceeds the static work memory's limit of %d",
+                c->cam.max_depth, ST_MAX_DEPTH);
+  if (order_entries(c) > ST_ORDER_ENTRIES)
+    return fail(c, RT_ERR_LIMIT, "rt_render_static_async: %zu packet-order entries exceed the limit of %zu",
+                order_entries(c), ST_ORDER_ENTRIES);
+  WorkMem m;
+  m.stats = reinterpret_cast<unsigned long long *>(base + ST_OFF_STATS);
+  m.tile_counter = reinterpret_cast<unsigned *>(base + ST_OFF_COUNTER);
+  m.block_hist = reinterpret_cast<unsigned *>(base + ST_OFF_HIST);
+  m.pclass = base + ST_OFF_PCLASS;
+  m.order = reinterpret_cast<int *>(base + ST_OFF_ORDER);
+  m.order_cap = ST_ORDER_ENTRIES;
+  m.acc = reinterpret_cast<long long *>(base + ST_OFF_ACC);
+  m.acc_pixels = local_pixels(c);   // the array keeps the last call's contents (any context's): always cleared
+  m.acc_known_clean = false;
+  m.queues = reinterpret_cast<float *>(base + ST_OFF_QUEUES);
+  m.queue_waves = ST_MAX_WAVES;
+  m.max_waves = ST_MAX_WAVES;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  return launch(c, flags, d_rgb, 0, d_ids, s, m);
 }
 
 int rt_assemble_async(rt_ctx *c, const float *d_gathered, int32_t nranks, size_t stride_floats,
@@ -744,7 +886,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   int n = std::min<int>(max_waves, 16384 + 8);  // the last 8 rows: phase sums of a profiling build
-  HIP_TRY(c, hipMemcpy(out, c->d_stats + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out, (c->last_stats ? c->last_stats : c->d_stats) + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 
@@ -756,7 +898,7 @@ int rt_collect(rt_ctx *c, void *stream, rt_stats *st) {
 
 int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_stats *st) {
   if (!c || !rgb_out) return RT_ERR_INVALID;
-  int rc = prepare(c, flags);
+  int rc = prepare(c);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   // (the two events of the whole-call bracket live in the context: nothing to leak on the
@@ -780,7 +922,7 @@ int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_s
   HIP_TRY(c, hipEventRecord(t0, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_rgb, 0, npx * 3 * sizeof(float), c->stream));
   if (ids_out) HIP_TRY(c, hipMemsetAsync(c->d_ids, 0xff, npx * c->spp * sizeof(uint32_t), c->stream));
-  rc = launch(c, flags, c->d_rgb, 0, ids_out ? c->d_ids : nullptr, c->stream);
+  rc = launch_own(c, flags, c->d_rgb, 0, ids_out ? c->d_ids : nullptr, c->stream);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (ids_out)
