@@ -28,13 +28,14 @@ struct rt_ctx {
   std::string err;
 
   // scene
-  float4 *d_nodes = nullptr, *d_prims = nullptr;
+  float4 *d_nodes = nullptr, *d_prims = nullptr, *d_wnodes = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
-  size_t cap_nodes = 0, cap_prims = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
+  size_t cap_nodes = 0, cap_prims = 0, cap_wnodes = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
   void *h_stage = nullptr;  // pinned staging buffer of the uploads
   size_t stage_cap = 0;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
+  int n_wnode_recs = 0, wide_stack = 0;  // wide records; most stack entries a wide traversal can hold at once
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
   int five_waves_mode = -1; // RT_FIVE_WAVES: 0 never use the 96-VGPR build
   bool have_scene = false;
@@ -225,6 +226,7 @@ struct Repack {
   std::string err;
 
   static void put_i(float *p, int v) { std::memcpy(p, &v, 4); }
+  static float as_f(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 
   // emits the records of a leaf (reversed list order), returns the leaf ref
   int emit_leaf(const rt_bvh_node &n) {
@@ -300,6 +302,66 @@ struct Repack {
     std::memcpy(d + 6, &sc->nodes[n.right].xmin, 24);
     put_i(d + 12, l);
     put_i(d + 13, r);
+    return me;
+  }
+};
+
+// Collapse of the binary device records (Repack::nodes) into wide records (rt_device.h).
+struct WideBuild {
+  const std::vector<float> &bin;  // 16 floats per binary record
+  std::vector<float> wide;        // 32 floats per wide record
+  int max_stack = 0;
+
+  struct Child { float box[6]; int ref; };
+  static int get_i(const float *p) { int v; std::memcpy(&v, p, 4); return v; }
+  static float area(const float *b) {
+    float w = b[1] - b[0], h = b[3] - b[2], d = b[5] - b[4];
+    return 2 * (w * h + w * d + h * d);
+  }
+  void children_of(int bidx, std::vector<Child> &out) const {
+    const float *r = &bin[(size_t)bidx * 16];
+    for (int k = 0; k < 2; ++k) {
+      int ref = get_i(r + 12 + k);
+      if (ref == REF_NONE) continue;
+      Child c;
+      std::memcpy(c.box, r + 6 * k, 24);
+      c.ref = ref;
+      out.push_back(c);
+    }
+  }
+  // returns the wide index built for binary record `bidx`; `stack_above` = entries that can sit on
+  // the traversal stack when this node is entered
+  int build(int bidx, int stack_above) {
+    std::vector<Child> ch;
+    children_of(bidx, ch);
+    while (ch.size() < 4) {
+      int best = -1;
+      float best_a = -1.0f;
+      for (size_t i = 0; i < ch.size(); ++i)
+        if (ch[i].ref >= 0) {
+          float a = area(ch[i].box);
+          if (!(a <= best_a)) { best_a = a; best = (int)i; }  // (NaN areas still get picked)
+        }
+      if (best < 0) break;
+      std::vector<Child> two;
+      children_of(ch[best].ref, two);
+      ch.erase(ch.begin() + best);
+      ch.insert(ch.begin() + best, two.begin(), two.end());
+    }
+    const int me = (int)(wide.size() / 32);
+    wide.resize(wide.size() + 32, 0.0f);
+    const int k = (int)ch.size();
+    // entering a child leaves at most k - 1 siblings on the stack
+    if (stack_above + k - 1 > max_stack) max_stack = stack_above + k - 1;
+    std::vector<int> refs(4, REF_NONE);
+    for (int i = 0; i < k; ++i)
+      refs[i] = ch[i].ref >= 0 ? build(ch[i].ref, stack_above + k - 1) : ch[i].ref;
+    float *w = &wide[(size_t)me * 32];
+    for (int i = 0; i < 4; ++i) {
+      const Child &c = ch[i < k ? i : 0];
+      for (int pl = 0; pl < 6; ++pl) w[pl * 4 + i] = c.box[pl];
+      std::memcpy(w + 24 + i, &refs[i], 4);
+    }
     return me;
   }
 };
@@ -482,17 +544,23 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.fd_n_grids = make_fastdiv((unsigned)p.n_grids);
   p.tile_counter = m.tile_counter;
   p.stats = m.stats;
-  p.stack_depth = c->stack_depth;
+  // pruned traversal walks the wide records (its stack holds up to wide_stack siblings, and the
+  // branch-free pushes may write one slot above the top); the reference-visit mode the binary tree
+  const bool prune = !(flags & RT_FLAG_NO_PRUNE);
+  const int stack_depth = prune ? std::max(4, (c->wide_stack + 1 + 3) & ~3) : c->stack_depth;
+  p.stack_depth = stack_depth;
+  p.wnodes = c->d_wnodes;
+  p.n_wnode_recs = c->n_wnode_recs;
   p.trace_zero_weight = (flags & RT_FLAG_TRACE_ZERO_WEIGHT) ? 1 : 0;
 
   LaunchCfg cfg{};
   cfg.block = 64 * WAVES_PER_BLOCK;
   cfg.mlight = c->n_lights > 1;
   p.point_words = cfg.mlight ? POINT_WORDS : 0;
-  cfg.lds_bytes = lds_bytes_for(c->stack_depth, p.point_words);
+  cfg.lds_bytes = lds_bytes_for(stack_depth, p.point_words);
   cfg.ev_k0 = c->timing ? c->evk0 : nullptr;
   cfg.ev_k1 = c->timing ? c->evk1 : nullptr;
-  cfg.prune = !(flags & RT_FLAG_NO_PRUNE);
+  cfg.prune = prune;
   cfg.count = (flags & RT_FLAG_COUNT_TESTS) != 0;
   // Small scenes (every shipped benchmark scene but bench3) are staged into each block's LDS:
   // node/primitive fetches then cost an LDS read instead of a trip through TA/L1.  The copy
@@ -500,16 +568,17 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.n_node_recs = c->n_node_recs;
   p.n_prim_recs = c->n_prim_recs;
   p.n_materials = c->n_materials;
-  cfg.lds_scene_bytes = (size_t)(c->n_node_recs + c->n_prim_recs) * LDS_REC_F4 * 16 +
+  p.lds_prim_base = prune ? c->n_wnode_recs * LDS_WNODE_F4 : c->n_node_recs * LDS_REC_F4;
+  cfg.lds_scene_bytes = ((size_t)p.lds_prim_base + (size_t)c->n_prim_recs * LDS_REC_F4) * 16 +
                         (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
   int wpb = WAVES_PER_BLOCK;
   if (!cfg.lds_scene && c->lds_scene_mode != 0 && !cfg.count && cfg.prune &&
-      lds_bytes_for(c->stack_depth, p.point_words, 8) + cfg.lds_scene_bytes <= 80 * 1024) {
+      lds_bytes_for(stack_depth, p.point_words, 8) + cfg.lds_scene_bytes <= 80 * 1024) {
     // too big beside four blocks' stacks, but two 8-wave blocks per CU can share one copy each
     wpb = 8;
     cfg.block = 512;
-    cfg.lds_bytes = lds_bytes_for(c->stack_depth, p.point_words, 8);
+    cfg.lds_bytes = lds_bytes_for(stack_depth, p.point_words, 8);
     cfg.lds_scene = true;
   }
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
@@ -522,7 +591,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
                    (c->five_waves_mode > 0 ||
                     (c->five_waves_mode < 0 && (long long)p.n_packets >= 64ll * c->n_cus * 20));
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  cfg.probe_lds_bytes = lds_bytes_for(c->stack_depth, p.point_words, WAVES_PER_BLOCK);
+  cfg.probe_lds_bytes = lds_bytes_for(stack_depth, p.point_words, WAVES_PER_BLOCK);
   int per_cu = fma ? occupancy_fma(cfg) : occupancy_strict(cfg);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
@@ -668,7 +737,7 @@ void rt_shutdown(rt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {c->d_nodes, c->d_prims, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
@@ -716,6 +785,12 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   int rc;
   if ((rc = upload(c, &c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
   if ((rc = upload(c, &c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
+  WideBuild wb{rp.nodes};
+  if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
+  else wb.wide.assign(32, 0.0f), std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
+  if ((rc = upload(c, &c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4))) return rc;
+  c->n_wnode_recs = (int)(wb.wide.size() / 32);
+  c->wide_stack = wb.max_stack;
   if ((rc = upload(c, &c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
   if ((rc = upload(c, &c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;

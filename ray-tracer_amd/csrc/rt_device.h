@@ -34,6 +34,20 @@ constexpr int NODE_F4 = 4;
 //   i[12] kind (0 sphere, 1 triangle)  i[13] material  i[14] object id
 //   i[15] number of records in this leaf (valid in the leaf's first record)
 constexpr int PRIM_F4 = 4;
+// WIDE node record (pruned traversal), 128 B = 8 x float4: up to FOUR children, collapsed at upload
+// from two levels of the binary tree (the child with the largest box is replaced by its own two
+// children until there are four).  One fetch decides four hitsBox tests and the dependent chain
+// pop -> fetch -> test -> descend is walked half as often.  Boxes are stored plane by plane,
+//   f4[0] xmin of the 4 children  f4[1] xmax   f4[2] ymin  f4[3] ymax   f4[4] zmin  f4[5] zmax
+//   f4[6] the 4 child refs (as in the binary record; REF_NONE = no such child, box = child 0's)
+// so that a ray whose direction sign on an axis is s reads its NEAR planes at f4[2a + s] and its
+// FAR planes at f4[2a + (s ^ 1)]: hitsBox's six sign selects per box (BoundingVolumeHierarchy.hs:
+// 194-199) become three per-ray address offsets.  Every primitive whose leaf box passes hitsBox is
+// still tested and no other: on the exact-quotient path a box's test implies its ancestors'
+// (monotone rounding), so skipping the collapsed levels' own boxes changes nothing; the closest hit
+// is order-independent under the total order of the tie rule.  Record 0 is the root.
+constexpr int WNODE_F4 = 8;
+constexpr int LDS_WNODE_F4 = 9;  // LDS stride of a wide record: 36 dwords, walks all sixteen 4-bank groups
 constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)
 
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
@@ -79,6 +93,8 @@ struct RenderParams {
   int *order;                            // ticket -> (packet << 7) | code, cost-sorted
   int probe_blocks, probe_span;          // blocks and packets per block (multiple of 256)
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
+  const float4 *wnodes;                  // wide node records (pruned traversal)
+  int n_wnode_recs, lds_prim_base;       // lds_prim_base: float4 offset of the primitive records in the LDS scene copy
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
   FastDiv fd_groups_per_tile, fd_tiles_x, fd_spp, fd_tile_w, fd_n_grids;  // the hot loop's divisors

@@ -213,7 +213,7 @@ DEVI const float4 *node_rec(const RenderParams &P, const float4 *sc, int idx) {
 }
 template <bool LDS>
 DEVI const float4 *prim_rec(const RenderParams &P, const float4 *sc, int idx) {
-  return LDS ? sc + (size_t)(P.n_node_recs + idx) * LDS_REC_F4 : P.prims + (size_t)idx * PRIM_F4;
+  return LDS ? sc + (P.lds_prim_base + idx * LDS_REC_F4) : P.prims + (size_t)idx * PRIM_F4;
 }
 
 // One inner node: both children's hitsBox tests, the (result-preserving) pruning and ordering,
@@ -254,6 +254,157 @@ DEVI void node_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
     cur = lref;
   } else if (hr) {
     cur = rref;
+  } else if (sp > 0) {
+    --sp;
+    cur = (int)stack[sp * 64 + lane];
+  } else {
+    cur = STOP;
+  }
+}
+
+// ---- wide (4-child) node step of the pruned traversal (record layout: rt_device.h) ----------
+// Per ray: sx, sy, sz = 1 where the direction component is negative (the reference's slab swap,
+// `d >= 0` is true for -0.0: BoundingVolumeHierarchy.hs:194-199), else 0.
+struct RaySign {
+  int x, y, z;
+};
+DEVI RaySign make_sign(V3 d) {
+  RaySign s;
+  s.x = d.x >= 0 ? 0 : 1;
+  s.y = d.y >= 0 ? 0 : 1;
+  s.z = d.z >= 0 ? 0 : 1;
+  return s;
+}
+template <bool LDS>
+DEVI const float4 *wnode_rec(const RenderParams &P, const float4 *sc, int idx) {
+  return LDS ? sc + idx * LDS_WNODE_F4 : P.wnodes + (size_t)idx * WNODE_F4;
+}
+// compare-exchange of (key, ref) pairs: afterwards ka <= kb
+DEVI void cswap(float &ka, int &ra, float &kb, int &rb) {
+  const bool sw = kb < ka;
+  const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+  const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+  ka = k0; kb = k1; ra = r0; rb = r1;
+}
+// entry / exit / verdict of the four child boxes of one record.
+//   MODE 0  first pass of the exact-quotient path; returns true if a verdict is in doubt
+//   MODE 1  correctly rounded quotients by Markstein's corrections (mdiv)
+//   MODE 2  plain divisions and the reference's six comparisons (zero / denormal direction
+//           components, out-of-range scenes)
+// The verdict `entry > exit` needs the correctly rounded quotients only when the two are within
+// rounding of each other.  First pass: q~ = RN(a * RN(1/d)), which is within 3.1 * 2^-24 |q~| of the
+// correctly rounded q = RN(a/d) (two roundings against one; no under/overflow on this path:
+// |d| in [2^-40, 2^40], a = 0 or in [2^-59, 2^60]); max and min keep that bound
+// (|entry - entry~| <= eps |entry~|, likewise exit; eps = 2^-22).  A slab's entry never exceeds its
+// OWN exit on this path (box min <= max, rounding is monotone) -- and for a flat box, an
+// axis-aligned triangle's, the two are one number in both arithmetics, so exit~ - entry~ = 0 exactly
+// whenever a ray hits it: that difference cannot be the yardstick.  The verdict is "every entry <=
+// every exit of ANOTHER axis", i.e. the smallest cross-axis gap
+//   g = min_j (exit_j - max_{i != j} entry_i) >= 0,
+// and with D = 2 eps (|entry~| + |exit~|):   g~ > D => hit,   g~ < -D => miss   (if the order of some
+// cross pair flipped under the roundings although |g~| > D, its two members would lie between
+// exit~ and entry~ and their error would be below D).  Only what is in doubt -- a ray grazing a box
+// edge to 7 digits -- is redone with the exact quotients: 6 multiplications and 8 more operations
+// per box instead of 30 fused ones, same verdicts bit for bit.  Pruning and ordering work on
+// entry~/exit~ (they have a 2^-12 margin).
+template <bool LDS, int MODE>
+DEVI bool wide_boxes(const RenderParams &P, const float4 *sc, int cur, V3 o, V3 d, const RayDiv &rd, const RaySign &sg,
+                     float &e0, float &e1, float &e2, float &e3, float &x0, float &x1, float &x2, float &x3, bool &h0,
+                     bool &h1, bool &h2, bool &h3) {
+  const float4 *np = wnode_rec<LDS>(P, sc, cur);
+  if (MODE == 2) {
+    const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5];
+    h0 = hits_box<false>(o, d, rd, a0.x, a1.x, a2.x, a3.x, a4.x, a5.x, e0, x0);
+    h1 = hits_box<false>(o, d, rd, a0.y, a1.y, a2.y, a3.y, a4.y, a5.y, e1, x1);
+    h2 = hits_box<false>(o, d, rd, a0.z, a1.z, a2.z, a3.z, a4.z, a5.z, e2, x2);
+    h3 = hits_box<false>(o, d, rd, a0.w, a1.w, a2.w, a3.w, a4.w, a5.w, e3, x3);
+    return false;
+  }
+  const float4 nx = np[sg.x], fx = np[sg.x ^ 1], ny = np[2 + sg.y], fy = np[2 + (sg.y ^ 1)], nz = np[4 + sg.z],
+               fz = np[4 + (sg.z ^ 1)];
+  constexpr float BAND = 4.76837158203125e-07f;  // 2 eps = 2^-21
+  bool doubt = false;
+#define RT_WIDE_CHILD(C_, E_, X_, H_)                                                                     \
+  {                                                                                                       \
+    if (MODE == 1) {                                                                                      \
+      const float tx0 = mdiv(nx.C_ - o.x, d.x, rd.rx), tx1 = mdiv(fx.C_ - o.x, d.x, rd.rx);               \
+      const float ty0 = mdiv(ny.C_ - o.y, d.y, rd.ry), ty1 = mdiv(fy.C_ - o.y, d.y, rd.ry);               \
+      const float tz0 = mdiv(nz.C_ - o.z, d.z, rd.rz), tz1 = mdiv(fz.C_ - o.z, d.z, rd.rz);               \
+      E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                   \
+      X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
+      H_ = !(E_ > X_);                                                                                    \
+    } else {                                                                                              \
+      const float tx0 = (nx.C_ - o.x) * rd.rx, tx1 = (fx.C_ - o.x) * rd.rx;                               \
+      const float ty0 = (ny.C_ - o.y) * rd.ry, ty1 = (fy.C_ - o.y) * rd.ry;                               \
+      const float tz0 = (nz.C_ - o.z) * rd.rz, tz1 = (fz.C_ - o.z) * rd.rz;                               \
+      const float mx = fmaxf(ty0, tz0), my = fmaxf(tx0, tz0), mz = fmaxf(tx0, ty0);                       \
+      E_ = fmaxf(tx0, mx);                                                                                \
+      X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
+      const float g = fminf(fminf(tx1 - mx, ty1 - my), tz1 - mz);                                         \
+      H_ = g >= 0;                                                                                        \
+      doubt |= fabsf(g) <= BAND * (fabsf(E_) + fabsf(X_));                                                \
+    }                                                                                                     \
+  }
+  RT_WIDE_CHILD(x, e0, x0, h0)
+  RT_WIDE_CHILD(y, e1, x1, h1)
+  RT_WIDE_CHILD(z, e2, x2, h2)
+  RT_WIDE_CHILD(w, e3, x3, h3)
+#undef RT_WIDE_CHILD
+  return doubt;
+}
+
+// Four hitsBox tests from one record, range pruning, then the children that remain go on the
+// stack farthest first and the nearest becomes current (or pop, or stop).  The stack writes are
+// unconditional -- a slot above the top is scratch -- so the step has no divergent pushes.
+template <bool COUNT, bool LDS>
+DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
+                    const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
+  float e0, e1, e2, e3, x0, x1, x2, x3;
+  bool h0, h1, h2, h3;
+  if (all_safe) {
+#ifdef RT_FAST_MATH
+    wide_boxes<LDS, 0>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
+#else
+    if (wide_boxes<LDS, 0>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3)) {
+      // (rare; the record is read again rather than kept in registers across the branch)
+      asm volatile("" ::: "memory");
+      wide_boxes<LDS, 1>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
+    }
+#endif
+  } else {
+    wide_boxes<LDS, 2>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
+  }
+  const float4 rf = wnode_rec<LDS>(P, sc, cur)[6];
+  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+  if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+  // range pruning as in node_step (a NaN entry/exit -- plain-division path only -- is ignored by
+  // max/min and never prunes)
+  const float lim = prune_limit(best_t);
+  h0 = h0 && r0 != REF_NONE && !(e0 > lim || x0 < BEHIND);
+  h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < BEHIND);
+  h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
+  h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
+  const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  // sort by entry distance, misses last (5 compare-exchanges)
+  // (a hit's key is capped below a miss's +inf -- also a NaN or +inf entry, which fminf turns into
+  //  FLT_MAX -- so that the n hits always end up in the first n places)
+  constexpr float KMAX = 3.4028234663852886e38f;
+  float k0 = h0 ? fminf(e0, KMAX) : INFINITY, k1 = h1 ? fminf(e1, KMAX) : INFINITY,
+        k2 = h2 ? fminf(e2, KMAX) : INFINITY, k3 = h3 ? fminf(e3, KMAX) : INFINITY;
+  cswap(k0, r0, k1, r1);
+  cswap(k2, r2, k3, r3);
+  cswap(k0, r0, k2, r2);
+  cswap(k1, r1, k3, r3);
+  cswap(k1, r1, k2, r2);
+  unsigned *sl = stack + sp * 64 + lane;
+  sl[0] = (unsigned)r3;
+  sl += (n >= 4) ? 64 : 0;
+  sl[0] = (unsigned)r2;
+  sl += (n >= 3) ? 64 : 0;
+  sl[0] = (unsigned)r1;
+  sp += (n >= 2 ? n - 1 : 0);
+  if (n >= 1) {
+    cur = r0;
   } else if (sp > 0) {
     --sp;
     cur = (int)stack[sp * 64 + lane];
@@ -307,6 +458,14 @@ DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
   }
 }
 
+// One inner-node step of either tree: the pruned traversal walks the wide records.
+template <bool PRUNE, bool COUNT, bool LDS>
+DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
+                     const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
+  if (PRUNE) wide_step<COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
+  else node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
+}
+
 template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
 DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, bool active, V3 o, V3 d,
                    float tlimit, float &best_t, int &best_p, Counters &cn) {
@@ -315,6 +474,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   int sp = 0;
   int cur = (active && P.has_root) ? 0 : STOP;
   const RayDiv rd = make_raydiv(P, o, d);
+  const RaySign sg = make_sign(d);
   // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
   // denormal direction component, or an out-of-range scene)
   const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
@@ -331,7 +491,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       if (at_node >= at_leaf) {
         if (cur >= 0) {
           DIV_COUNT(cn, ANY ? 2 : 0);
-          node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
+          inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
         }
       } else if (cur < 0 && cur != STOP) {
         DIV_COUNT(cn, ANY ? 3 : 1);
@@ -343,7 +503,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   while (cur != STOP) {
     while (cur >= 0) {
       DIV_COUNT(cn, ANY ? 2 : 0);
-      node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
+      inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
     }
     if (cur != STOP) {
       DIV_COUNT(cn, ANY ? 3 : 1);
@@ -429,6 +589,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   RayDiv rd;
   rd.rx = rd.ry = rd.rz = 1.0f;
   rd.safe = true;
+  RaySign sg = make_sign(d);
   for (;;) {
     const unsigned long long idle = __ballot(cur == STOP);
     if (remaining > 0 && (~idle == 0ull || __popcll(idle) >= P.rearm_min)) {
@@ -455,6 +616,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
         light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
                   tlimit);
         rd = make_raydiv(P, o, d);
+        sg = make_sign(d);
         sp = 0;
         cur = 0;
       }
@@ -466,7 +628,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
     if (at_node >= at_leaf) {
       if (cur >= 0) {
         DIV_COUNT(cn, 2);
-        node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, tlimit, cur, sp, cn);
+        inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, tlimit, cur, sp, cn);
       }
     } else if (cur < 0 && cur != STOP) {
       DIV_COUNT(cn, 3);
@@ -684,19 +846,28 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
-  const int rec_words = LDS ? (P.n_node_recs + P.n_prim_recs) * LDS_REC_F4 * 4 : 0;
+  const int rec_words = LDS ? (P.lds_prim_base + P.n_prim_recs * LDS_REC_F4) * 4 : 0;
   const int mat_words = LDS ? ((P.n_materials * 12 + 3) & ~3) : 0;
   const int scene_words = rec_words + mat_words;
   const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
   if (LDS) {
-    // the block's one and only barrier: stage the scene (a few KB) once per persistent block
+    // the block's one and only barrier: stage the scene (a few KB) once per persistent block --
+    // the inner nodes of the tree this build walks (wide records when pruning), then the primitives
     float4 *dst = reinterpret_cast<float4 *>(lds);
-    const int n_f4 = (P.n_node_recs + P.n_prim_recs) * 4;
-    for (int i = threadIdx.x; i < n_f4; i += 64 * WPB) {
+    if (PRUNE) {
+      for (int i = threadIdx.x; i < P.n_wnode_recs * 7; i += 64 * WPB) {
+        const int rec = i / 7, part = i - rec * 7;
+        dst[rec * LDS_WNODE_F4 + part] = P.wnodes[(size_t)rec * WNODE_F4 + part];
+      }
+    } else {
+      for (int i = threadIdx.x; i < P.n_node_recs * 4; i += 64 * WPB) {
+        const int rec = i >> 2, part = i & 3;
+        dst[rec * LDS_REC_F4 + part] = P.nodes[(size_t)rec * NODE_F4 + part];
+      }
+    }
+    for (int i = threadIdx.x; i < P.n_prim_recs * 4; i += 64 * WPB) {
       const int rec = i >> 2, part = i & 3;
-      const float4 v = rec < P.n_node_recs ? P.nodes[(size_t)rec * NODE_F4 + part]
-                                           : P.prims[(size_t)(rec - P.n_node_recs) * PRIM_F4 + part];
-      dst[(size_t)rec * LDS_REC_F4 + part] = v;
+      dst[P.lds_prim_base + rec * LDS_REC_F4 + part] = P.prims[(size_t)rec * PRIM_F4 + part];
     }
     for (int i = threadIdx.x; i < P.n_materials * 12; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
     __syncthreads();
