@@ -311,6 +311,24 @@ struct WideBuild {
   const std::vector<float> &bin;  // 16 floats per binary record
   std::vector<float> wide;        // 32 floats per wide record
   int max_stack = 0;
+  // Most entries the traversal stack may ever hold.  A wide node leaves up to 3 siblings on the
+  // stack per level instead of the binary tree's 1, and the per-lane stacks are LDS: 27 entries
+  // (+1 scratch slot) is what still lets four blocks share a CU beside the shadow-ray pool.  Where a
+  // path would exceed the cap the collapse stops early (fewer children per node); a binary
+  // continuation needs one entry per remaining level, so cap >= the binary tree's depth suffices.
+  int cap = 27;
+  std::vector<int> height;        // of the binary subtree under each binary record (leaf children = 0)
+
+  int height_of(int bidx) {
+    if (height[bidx] >= 0) return height[bidx];
+    int h = 0;
+    const float *r = &bin[(size_t)bidx * 16];
+    for (int k = 0; k < 2; ++k) {
+      int ref = get_i(r + 12 + k);
+      if (ref >= 0) h = std::max(h, 1 + height_of(ref));
+    }
+    return height[bidx] = h;
+  }
 
   struct Child { float box[6]; int ref; };
   static int get_i(const float *p) { int v; std::memcpy(&v, p, 4); return v; }
@@ -335,6 +353,12 @@ struct WideBuild {
     std::vector<Child> ch;
     children_of(bidx, ch);
     while (ch.size() < 4) {
+      // one more child = one more sibling on the stack for every path below: allowed while the
+      // deepest path below (one entry per remaining binary level) still fits under the cap
+      int below = 0;
+      for (const Child &c : ch)
+        if (c.ref >= 0) below = std::max(below, 1 + height_of(c.ref));
+      if (stack_above + (int)ch.size() + below > cap) break;
       int best = -1;
       float best_a = -1.0f;
       for (size_t i = 0; i < ch.size(); ++i)
@@ -786,11 +810,16 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if ((rc = upload(c, &c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
   if ((rc = upload(c, &c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
   WideBuild wb{rp.nodes};
+  wb.cap = std::max(27, rp.max_depth);
+  wb.height.assign(rp.nodes.size() / 16, -1);
   if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
   else wb.wide.assign(32, 0.0f), std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
   if ((rc = upload(c, &c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4))) return rc;
   c->n_wnode_recs = (int)(wb.wide.size() / 32);
   c->wide_stack = wb.max_stack;
+  if (std::getenv("RT_DEBUG_UPLOAD"))
+    std::fprintf(stderr, "[rt_upload_scene] binary records %zu (depth %d), wide records %d, wide stack need %d (cap %d), primitives %zu\n",
+                 rp.nodes.size() / 16, rp.max_depth, c->n_wnode_recs, wb.max_stack, wb.cap, rp.prims.size() / 16);
   if ((rc = upload(c, &c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
   if ((rc = upload(c, &c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
   c->n_lights = sc->n_lights;
