@@ -241,6 +241,12 @@ int rt_render_tiles_async(rt_ctx *ctx, uint32_t flags, float *d_tiles, void *hip
 int rt_assemble_async(rt_ctx *ctx, const float *d_gathered, int32_t nranks,
                       size_t stride_floats, float *d_rgb, void *hip_stream);
 
+/* The same for frames quantised BEFORE the exchange (rt_quantize_async on each rank's compact
+ * tile buffer, then a gather of bytes: a quarter of the traffic into the root): 8-bit compact
+ * buffers, `stride_bytes` bytes apart, into d_rgb8 (img_w*img_h*3 bytes). */
+int rt_assemble8_async(rt_ctx *ctx, const uint8_t *d_gathered8, int32_t nranks, size_t stride_bytes,
+                       uint8_t *d_rgb8, void *hip_stream);
+
 /* Wait for the stream of the last render call and fill stats (ray counters and
  * ms_kernel of that call). */
 int rt_collect(rt_ctx *ctx, void *hip_stream, rt_stats *stats);
@@ -275,6 +281,34 @@ int rt_wave_diag(rt_ctx *ctx, uint64_t *out, int32_t max_waves);
 
 const char *rt_last_error(rt_ctx *ctx);
 int rt_abi_version(void);
+
+/* ---- one host process, N GPUs ------------------------------------------ */
+
+/* What a single-process host (the Haskell program is one) needs to render ONE frame on the N
+ * GPUs of a node: SURVEY.md 8(b)'s `rt_init(n_gpus)` and BASELINE.json's "image tiles split
+ * statically across the GPUs, framebuffer assembled with an RCCL gather over xGMI".  No
+ * counterpart in the reference (render is one sequential map, src/RayTracer.hs:23).  An rt_multi
+ * owns one rt_ctx per GPU; scene, camera and samples are replicated; tile t of the frame
+ * (rt_get_tiling) is rendered by rank t % N; the ranks' compact tile buffers are gathered on rank
+ * 0 with grouped RCCL point-to-point transfers (every peer has its own xGMI link into rank 0) and
+ * scattered into the frame.  The frame is bitwise identical for every N.
+ * devices: n_gpus HIP device ids, NULL = 0..n_gpus-1.  Ids may repeat (a rehearsal of the N-rank
+ * data path on fewer GPUs): the exchange then uses device-to-device copies instead of RCCL, which
+ * refuses duplicate devices.  RCCL is loaded at run time by this call only.
+ * On failure *out is still set when possible, so that rt_multi_last_error can be read; free it
+ * with rt_multi_shutdown. */
+typedef struct rt_multi rt_multi;
+int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out);
+void rt_multi_shutdown(rt_multi *m);
+int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene);
+int rt_multi_set_camera(rt_multi *m, const rt_camera *cam);
+int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t spp);
+/* render on all GPUs (blocking).  rgb_out: img_w*img_h*3 floats as rt_render, or NULL;
+ * rgb8_out: the frame as writePPM quantises it (src/Main.hs:99-101,131), img_w*img_h*3 bytes, or
+ * NULL; at least one of them.  With rgb8_out alone every rank quantises its own tiles and BYTES are
+ * gathered.  stats (may be NULL): sums over the ranks; times = the slowest rank's.  Host pointers. */
+int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out, rt_stats *stats);
+const char *rt_multi_last_error(rt_multi *m);
 
 #ifdef __cplusplus
 }

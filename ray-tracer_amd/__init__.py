@@ -115,6 +115,8 @@ DEVICE_SYMBOLS = [
     "rt_set_partition", "rt_get_tiling", "rt_render", "rt_render_async", "rt_render_tiles_async",
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
     "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing", "rt_render_static_async",
+    "rt_assemble8_async", "rt_multi_init", "rt_multi_shutdown", "rt_multi_upload_scene", "rt_multi_set_camera",
+    "rt_multi_set_samples", "rt_multi_render", "rt_multi_last_error",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -221,6 +223,16 @@ def device_lib() -> C.CDLL:
         L.rt_render_tiles_async.argtypes = [vp, u32, vp, vp]
         L.rt_render_static_async.argtypes = [vp, u32, vp, vp, vp]
         L.rt_assemble_async.argtypes = [vp, vp, i32, C.c_size_t, vp, vp]
+        L.rt_assemble8_async.argtypes = [vp, vp, i32, C.c_size_t, vp, vp]
+        L.rt_multi_init.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+        L.rt_multi_shutdown.argtypes = [vp]
+        L.rt_multi_shutdown.restype = None
+        L.rt_multi_upload_scene.argtypes = [vp, C.POINTER(SceneView)]
+        L.rt_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.rt_multi_set_samples.argtypes = [vp, C.POINTER(f32), i32, i32]
+        L.rt_multi_render.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(C.c_uint8), C.POINTER(Stats)]
+        L.rt_multi_last_error.argtypes = [vp]
+        L.rt_multi_last_error.restype = C.c_char_p
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
         L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
         L.rt_wave_diag.argtypes = [vp, C.POINTER(u64), i32]
@@ -542,6 +554,62 @@ class Renderer:
     def close(self) -> None:
         if self._h:
             self.lib.rt_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """One rt_multi: one host process rendering each frame on N GPUs (tiles t % N, RCCL gather
+    on rank 0).  `devices` may repeat ids to rehearse the N-rank data path on fewer GPUs."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.lib = device_lib()
+        h = C.c_void_p()
+        arr = (i32 * len(devices))(*devices)
+        rc = self.lib.rt_multi_init(len(devices), arr, C.byref(h))
+        self._h = h if h else None
+        if rc != 0:
+            msg = self.lib.rt_multi_last_error(h).decode() if h else ""
+            self.close()
+            raise RtError(f"rt_multi_init({list(devices)}) failed with {rc}: {msg}")
+        self.world: Optional[World] = None
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            msg = self.lib.rt_multi_last_error(self._h)
+            raise RtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_world(self, world: World) -> None:
+        self._check(self.lib.rt_multi_upload_scene(self._h, C.byref(world.scene.view)), "rt_multi_upload_scene")
+        self._check(self.lib.rt_multi_set_camera(self._h, C.byref(world.camera)), "rt_multi_set_camera")
+        self.world = world
+
+    def set_samples(self, grids: np.ndarray) -> None:
+        g = np.ascontiguousarray(grids, np.float32)
+        self._check(self.lib.rt_multi_set_samples(self._h, g.ctypes.data_as(C.POINTER(f32)), g.shape[0],
+                                                  g.shape[1]), "rt_multi_set_samples")
+
+    def render(self, flags: int = 0, want_float: bool = True, want_8bit: bool = False):
+        """Returns (rgb [H*W,3] f32 or None, rgb8 [H*W,3] u8 or None, Stats)."""
+        w = self.world
+        assert w is not None and (want_float or want_8bit)
+        rgb = np.zeros((w.height * w.width, 3), np.float32) if want_float else None
+        rgb8 = np.zeros((w.height * w.width, 3), np.uint8) if want_8bit else None
+        st = Stats()
+        self._check(self.lib.rt_multi_render(self._h, flags,
+                                             rgb.ctypes.data_as(C.POINTER(f32)) if want_float else None,
+                                             rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_8bit else None,
+                                             C.byref(st)), "rt_multi_render")
+        return rgb, rgb8, st
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.rt_multi_shutdown(self._h)
             self._h = None
 
     def __del__(self):

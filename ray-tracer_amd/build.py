@@ -55,6 +55,7 @@ def build_device(force=False, defines=(), tag="", cflags=()):
         ("rt_kernels_strict", ["-ffp-contract=off"], [kern]),
         ("rt_kernels_fma", ["-ffp-contract=fast"], [kern]),
         ("rt_api", ["-ffp-contract=off"], []),
+        ("rt_multi", ["-ffp-contract=off"], []),
     ]
     base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
     base += ["-D" + d for d in defines] + list(cflags)
@@ -68,12 +69,27 @@ def build_device(force=False, defines=(), tag="", cflags=()):
             relink = True
         objs.append(o)
     if relink or _stale(out, objs):
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out])
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out])
+    return out
+
+
+def build_harness(force=False):
+    """integration/rt_harness.c: the C ABI driven from plain C (gcc), linked against the two
+    libraries only (run by tests/test_gpu_multi.py on the GPU box)."""
+    src = os.path.join(ROOT, "integration", "rt_harness.c")
+    out = os.path.join(LIB, "rt_harness")
+    deps = [src, os.path.join(INC, "rt_host.h"), os.path.join(INC, "rt_mi355x.h"),
+            os.path.join(LIB, "librt_host.so"), os.path.join(LIB, "librt_mi355x.so")]
+    if force or _stale(out, deps):
+        _run(["gcc", "-std=c11", "-O2", "-Wall", "-I" + INC, src, "-L" + LIB, "-lrt_mi355x", "-lrt_host",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB, "-o", out])
     return out
 
 
 def build_all(force=False):
-    return build_host(force), build_device(force)
+    h, d = build_host(force), build_device(force)
+    build_harness(force)
+    return h, d
 
 
 if __name__ == "__main__":

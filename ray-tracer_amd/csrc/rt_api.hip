@@ -390,8 +390,9 @@ struct WideBuild {
   }
 };
 
-__global__ void assemble_kernel(const float *__restrict__ gathered, int nranks, size_t stride,
-                                float *__restrict__ rgb, int W, int H, int tile_w, int tile_h,
+template <class T>
+__global__ void assemble_kernel(const T *__restrict__ gathered, int nranks, size_t stride,
+                                T *__restrict__ rgb, int W, int H, int tile_w, int tile_h,
                                 int tiles_x, int n_tiles) {
   const int tile_px = tile_w * tile_h;
   size_t total = (size_t)n_tiles * tile_px;
@@ -402,8 +403,8 @@ __global__ void assemble_kernel(const float *__restrict__ gathered, int nranks, 
     int py = (gt / tiles_x) * tile_h + pit / tile_w;
     if (px >= W || py >= H) continue;
     int rank = gt % nranks, l = gt / nranks;
-    const float *s = gathered + (size_t)rank * stride + ((size_t)l * tile_px + pit) * 3;
-    float *d = rgb + ((size_t)py * W + px) * 3;
+    const T *s = gathered + (size_t)rank * stride + ((size_t)l * tile_px + pit) * 3;
+    T *d = rgb + ((size_t)py * W + px) * 3;
     d[0] = s[0];
     d[1] = s[1];
     d[2] = s[2];
@@ -933,25 +934,38 @@ int rt_render_static_async(rt_ctx *c, uint32_t flags, float *d_rgb, uint32_t *d_
   return launch(c, flags, d_rgb, 0, d_ids, s, m);
 }
 
-int rt_assemble_async(rt_ctx *c, const float *d_gathered, int32_t nranks, size_t stride_floats,
-                      float *d_rgb, void *stream) {
+}  // extern "C"
+
+template <class T>
+static int assemble_any(rt_ctx *c, const T *d_gathered, int32_t nranks, size_t stride, T *d_rgb, void *stream) {
   if (!c || !d_gathered || !d_rgb || nranks < 1) return RT_ERR_INVALID;
   if (!c->have_cam || !c->have_samples) return fail(c, RT_ERR_STATE, "camera and samples must be set first");
   HIP_TRY(c, hipSetDevice(c->device));
   compute_tiling(c);
   const rt_tiling &t = c->tiling;
-  size_t tile_floats = (size_t)t.tile_w * t.tile_h * 3;
+  size_t tile_elems = (size_t)t.tile_w * t.tile_h * 3;
   size_t max_local = (size_t)(t.n_tiles + nranks - 1) / nranks;
-  if (stride_floats < max_local * tile_floats)
-    return fail(c, RT_ERR_INVALID, "stride_floats %zu smaller than a rank's tile buffer %zu", stride_floats,
-                max_local * tile_floats);
+  if (stride < max_local * tile_elems)
+    return fail(c, RT_ERR_INVALID, "stride %zu smaller than a rank's tile buffer %zu", stride, max_local * tile_elems);
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   size_t total = (size_t)t.n_tiles * t.tile_w * t.tile_h;
   int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(256), 0, s, d_gathered, nranks, stride_floats, d_rgb,
+  hipLaunchKernelGGL(assemble_kernel<T>, dim3(grid), dim3(256), 0, s, d_gathered, nranks, stride, d_rgb,
                      c->cam.img_w, c->cam.img_h, t.tile_w, t.tile_h, t.tiles_x, t.n_tiles);
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
+}
+
+extern "C" {
+
+int rt_assemble_async(rt_ctx *c, const float *d_gathered, int32_t nranks, size_t stride_floats, float *d_rgb,
+                      void *stream) {
+  return assemble_any<float>(c, d_gathered, nranks, stride_floats, d_rgb, stream);
+}
+
+int rt_assemble8_async(rt_ctx *c, const uint8_t *d_gathered8, int32_t nranks, size_t stride_bytes, uint8_t *d_rgb8,
+                       void *stream) {
+  return assemble_any<uint8_t>(c, d_gathered8, nranks, stride_bytes, d_rgb8, stream);
 }
 
 int rt_quantize_async(rt_ctx *c, const float *d_rgb, uint8_t *d_rgb8, size_t n, void *stream) {

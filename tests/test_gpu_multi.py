@@ -1,0 +1,86 @@
+"""The N-GPU form of the C ABI (rt_multi_*, include/rt_mi355x.h): one host process, one rt_ctx
+per GPU, tiles t % N, one exchange step per frame (RCCL point-to-point gather on rank 0), assembly.
+A one-GPU box can run (i) N = 1 through RCCL itself (library binding, communicator, grouped
+send/recv on the render stream) and (ii) N > 1 ranks SHARING the GPU, where the exchange falls back
+to device-to-device copies -- same buffers, strides and ordering as the RCCL branch.  More GPUs are
+the driver's to run.  Frames must equal the single-context frame bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import make_world
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def single(rt, world, grids, flags=0):
+    r = rt.Renderer(0)
+    try:
+        r.set_world(world)
+        r.set_samples(grids)
+        rgb, _, st = r.render(flags)
+        return rgb, st
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0], [0] * 8])
+def test_multi_frame_is_bitwise_the_single_context_frame(rt, devices):
+    m = rt.MultiRenderer(devices)
+    try:
+        # two frames in a row on one rt_multi: 200x150 (sides not multiples of the 16x16 tiles), then
+        # a larger frame of another scene (buffers grow), 8-bit gather included
+        for name, w, h, rpp, seed in (("bench1", 200, 150, 4, 9), ("bench2", 320, 200, 16, 5)):
+            world = make_world(rt, name, w, h, rpp)
+            grids = rt.generate_grids(seed, w + 10, world.camera.aa)
+            ref, ref_st = single(rt, world, grids)
+            m.set_world(world)
+            m.set_samples(grids)
+            rgb, _, st = m.render(0)
+            assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32))
+            assert (st.rays_primary, st.rays_shadow, st.rays_reflection, st.rays_refraction, st.primary_hits) == \
+                   (ref_st.rays_primary, ref_st.rays_shadow, ref_st.rays_reflection, ref_st.rays_refraction,
+                    ref_st.primary_hits)
+            _, rgb8, _ = m.render(0, want_float=False, want_8bit=True)       # ranks quantise, bytes are gathered
+            assert np.array_equal(rgb8, rt.quantize(ref))
+            both_f, both_8, _ = m.render(0, want_float=True, want_8bit=True)  # floats gathered, root quantises
+            assert np.array_equal(both_f.view(np.uint32), ref.view(np.uint32)) and np.array_equal(both_8, rgb8)
+    finally:
+        m.close()
+
+
+def test_multi_reports_errors(rt):
+    with pytest.raises(rt.RtError, match="rt_init"):
+        rt.MultiRenderer([0, 4711])                    # no such GPU
+    m = rt.MultiRenderer([0, 0])
+    try:
+        with pytest.raises(rt.RtError, match="camera and samples"):
+            m.world = make_world(rt, "bench1", 32, 24, 1)
+            m.render(0)
+    finally:
+        m.close()
+
+
+def test_c_harness_drives_the_abi_from_plain_c(rt, oracle, tmp_path):
+    """integration/rt_harness.c (gcc, no Python, no torch): host library -> World, device library
+    -> frame, writePPM; plus the rt_multi path with one GPU through RCCL.  The P3 file it writes
+    must be the oracle's frame to the parity bar."""
+    exe = os.path.join(ROOT, "ray-tracer_amd", "lib", "rt_harness")
+    assert os.path.exists(exe), "rt_harness not built (run __graft_entry__.build())"
+    out = os.path.join(tmp_path, "img.ppm")
+    p = subprocess.run([exe, "bench1", "160", "120", "4", out, "1"], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-1000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("scene=")][-1]   # (RCCL may print banners of its own)
+    kv = dict(x.split("=") for x in line.split())
+    assert kv["multi_frame_identical"] == "1" and kv["multi_8bit_identical"] == "1"
+    toks = open(out).read().split()
+    assert toks[:4] == ["P3", "160", "120", "255"]
+    img = np.array(toks[4:], np.int32).reshape(-1, 3)
+    world = make_world(rt, "bench1", 160, 120, 4)
+    grids = rt.generate_grids(2024, 170, 2)
+    o_rgb, _, o_st = oracle.render(world, grids, oracle.FLAG_CULL_ZERO_WEIGHT, want_hit_ids=False)
+    assert int(kv["rays"]) == o_st.rays_total == int(kv["multi_rays"])
+    assert np.abs(img - rt.quantize(o_rgb).astype(np.int32)).max() <= 1
