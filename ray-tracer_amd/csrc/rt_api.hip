@@ -662,6 +662,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     HIP_TRY(c, hipMemsetAsync(m.acc, 0, m.acc_pixels * 3 * sizeof(long long), s));
   c->last_stats = m.stats;
   if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
+  (void)hipGetLastError();  // the check below is for THESE launches, not for a stale error of the process
   if (fma) launch_render_fma(p, cfg, s);
   else launch_render_strict(p, cfg, s);
   HIP_TRY(c, hipGetLastError());

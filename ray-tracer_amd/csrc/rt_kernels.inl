@@ -157,13 +157,16 @@ DEVI bool hit_sphere(V3 base, V3 dir, float4 q0, float r2, float &t_out) {
   float discriminant = dec * dec - dirdir * (ecec - r2);
   if (!(discriminant > 0)) { t_out = 0.0f; return false; }  // same verdict, skips sqrt + 2 divisions
   float disc_val = sqrtf(discriminant);
-  V3 neg_dir = multiply(dir, -1.0f);
-  float neg_dir_ec = dot(neg_dir, ec);
-  float t_a = (neg_dir_ec + disc_val) / dirdir;
-  float t_b = (neg_dir_ec - disc_val) / dirdir;
-  float t = hs_min(t_a, t_b);
+  // neg_dir_ec = dot (dir * (-1)) ec (:346-347) is -dec bit for bit: negation commutes with every
+  // rounding of the products and sums (a zero sum may differ in SIGN only, and disc_val > 0 is
+  // added to it).
+  float neg_dir_ec = -dec;
+  // t = min t_a t_b (:350) is t_b: disc_val > 0 and dirdir > 0 here (discriminant > 0 rules out a
+  // zero or NaN direction), so RN(n - s) <= RN(n + s) and division by dirdir keeps the order; when
+  // the two are equal `min` returns the same number.  One division instead of two.
+  float t = (neg_dir_ec - disc_val) / dirdir;
   t_out = t;
-  return discriminant > 0 && t > EPSILON;
+  return t > EPSILON;
 }
 
 // hit, triangle (RayTracer.hs:354-380); A, A-B, A-C, N precomputed at upload

@@ -120,11 +120,12 @@ int mfail(rt_multi *m, int code, const char *fmt, ...) {
 
 void free_frame_buffers(rt_multi *m) {
   for (int r = 0; r < m->n; ++r) {
+    if (!m->ctx[r]) continue;  // (a rank whose rt_init failed: its device id may not even exist)
     (void)hipSetDevice(m->devices[r]);
     if (r > 0 && r < (int)m->d_tiles.size() && m->d_tiles[r]) (void)hipFree(m->d_tiles[r]);
     if (r > 0 && r < (int)m->d_tiles8.size() && m->d_tiles8[r]) (void)hipFree(m->d_tiles8[r]);
   }
-  if (m->n) (void)hipSetDevice(m->devices[0]);
+  if (m->n && m->ctx[0]) (void)hipSetDevice(m->devices[0]);
   for (void *p : {(void *)m->d_gathered, (void *)m->d_rgb, (void *)m->d_gathered8, (void *)m->d_rgb8})
     if (p) (void)hipFree(p);
   m->d_gathered = m->d_rgb = nullptr;
@@ -213,7 +214,7 @@ int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out) {
 void rt_multi_shutdown(rt_multi *m) {
   if (!m) return;
   for (int r = 0; r < m->n; ++r)
-    if (m->stream[r]) {
+    if (m->ctx[r] && m->stream[r]) {
       (void)hipSetDevice(m->devices[r]);
       (void)hipStreamSynchronize(m->stream[r]);
     }
@@ -221,10 +222,12 @@ void rt_multi_shutdown(rt_multi *m) {
     if (c) (void)m->rccl.CommDestroy(c);
   free_frame_buffers(m);
   for (int r = 0; r < m->n; ++r) {
+    if (!m->ctx[r]) continue;
     (void)hipSetDevice(m->devices[r]);
     if (m->done[r]) (void)hipEventDestroy(m->done[r]);
-    if (m->ctx[r]) rt_shutdown(m->ctx[r]);
+    rt_shutdown(m->ctx[r]);
   }
+  (void)hipGetLastError();  // leave no stale error behind for the process's next HIP call
   delete m;
 }
 
