@@ -77,6 +77,25 @@ int rth_config_to_camera(const rth_config *cfg, rt_camera *out);
  * `seed`), not the reference's unpinned package stack. */
 int rth_generate_grids(uint64_t seed, int32_t n_grids, int32_t aa, float *out);
 
+/* generateGrids for `rng = pureMT seed`, SEED-LEVEL: the stream a GHC build of
+ * the reference produces from that seed, restated from the PUBLISHED algorithms of the three
+ * packages it imports (none is in /root/reference; ray-tracer.cabal:39-41 gives no versions;
+ * pinned here to the ones current when the reference was written, 2014/15):
+ *   mersenne-random-pure64 0.2.0.4  pureMT = init_genrand64; randomWord64 = genrand64_int64;
+ *       randomDouble = (w `div` 2048) / 2^53; `next` = randomInt = the same word as Int;
+ *       genRange = (minBound, maxBound)
+ *   random 1.1                      randomR (0,i) on Int = randomIvalInteger: with b = 2^64 >=
+ *       1000 (i+1) ONE draw x, result (x - minBound) `mod` (i+1)
+ *   random-shuffle 0.0.4            shuffle' xs n g: r_j = randomR (0, n-j) for j = 1..n-1 threaded
+ *       through g; output = repeatedly extract the r_j-th of what remains
+ * and from the call sites: grid k draws its 2 aa^2 floats from `randomFloats rng` at position
+ * 2 aa^2 k and shuffles with `iterate (snd . next) rng !! k`, i.e. the SAME stream entered k
+ * words in, for both shuffles (src/RayTracer.hs:462-481).  PARITY UNPINNED: no GHC, no package
+ * sources and no recorded (seed, output) pair exist to check this against. */
+int rth_generate_grids_pure64(uint64_t seed, int32_t n_grids, int32_t aa, float *out);
+/* The first n words of that stream (genrand64_int64 after init_genrand64(seed)), for known-answer tests. */
+int rth_mt19937_64(uint64_t seed, int32_t n, uint64_t *out);
+
 /* writePPM (src/Main.hs:128-138) and its 8-bit quantisation. */
 int rth_write_ppm(const char *path, int32_t w, int32_t h, const float *rgb);
 void rth_quantize(const float *rgb, size_t n, uint8_t *out);

@@ -124,7 +124,7 @@ HOST_SYMBOLS = [
     "rth_scene_view", "rth_scene_n_objects", "rth_scene_bvh_depth", "rth_default_config",
     "rth_config_to_camera", "rth_generate_grids", "rth_write_ppm", "rth_quantize",
     "rth_write_ppm_binary",
-    "rth_material_by_name", "rth_make_triangle",
+    "rth_material_by_name", "rth_make_triangle", "rth_generate_grids_pure64", "rth_mt19937_64",
 ]
 
 
@@ -165,6 +165,8 @@ def host_lib() -> C.CDLL:
         L.rth_default_config.argtypes = [C.c_char_p, C.POINTER(HostConfig)]
         L.rth_config_to_camera.argtypes = [C.POINTER(HostConfig), C.POINTER(Camera)]
         L.rth_generate_grids.argtypes = [u64, i32, i32, C.POINTER(f32)]
+        L.rth_generate_grids_pure64.argtypes = [u64, i32, i32, C.POINTER(f32)]
+        L.rth_mt19937_64.argtypes = [u64, i32, C.POINTER(u64)]
         L.rth_write_ppm.argtypes = [C.c_char_p, i32, i32, C.POINTER(f32)]
         L.rth_quantize.argtypes = [C.POINTER(f32), C.c_size_t, C.POINTER(C.c_uint8)]
         L.rth_quantize.restype = None
@@ -408,6 +410,23 @@ def generate_grids(seed: int, num: int, aa: int) -> np.ndarray:
     rc = host_lib().rth_generate_grids(seed, num, aa, out.ctypes.data_as(C.POINTER(f32)))
     if rc != 0:
         raise RtError("generate_grids failed")
+    return out
+
+
+def generate_grids_pure64(seed: int, num: int, aa: int) -> np.ndarray:
+    """generateGrids (pureMT seed) num aa, seed-level: the table a GHC build of the reference would
+    produce from that seed with mersenne-random-pure64 0.2 / random 1.1 / random-shuffle 0.0.4
+    (restated from the packages' published algorithms; PARITY UNPINNED, see include/rt_host.h)."""
+    out = np.empty((num, aa * aa, 6), np.float32)
+    if host_lib().rth_generate_grids_pure64(seed, num, aa, out.ctypes.data_as(C.POINTER(f32))) != 0:
+        raise RtError("generate_grids_pure64 failed")
+    return out
+
+
+def mt19937_64(seed: int, n: int) -> np.ndarray:
+    out = np.empty(n, np.uint64)
+    if host_lib().rth_mt19937_64(seed, n, out.ctypes.data_as(C.POINTER(u64))) != 0:
+        raise RtError("mt19937_64 failed")
     return out
 
 

@@ -1021,6 +1021,101 @@ int rth_generate_grids(uint64_t seed, int32_t n_grids, int32_t aa, float *out) {
   return RT_OK;
 }
 
+// ---- seed-level generateGrids (see include/rt_host.h for the package algorithms followed) ----
+namespace {
+// MT19937-64 (Matsumoto & Nishimura, mt19937-64.c 2004/9/29), written out rather than taken
+// from <random> so that every constant of the published algorithm is visible and testable.
+struct PureMT64 {
+  static constexpr int NN = 312, MM = 156;
+  uint64_t mt[NN];
+  int mti;
+  explicit PureMT64(uint64_t seed) {                     // init_genrand64
+    mt[0] = seed;
+    for (mti = 1; mti < NN; ++mti) mt[mti] = 6364136223846793005ull * (mt[mti - 1] ^ (mt[mti - 1] >> 62)) + (uint64_t)mti;
+  }
+  uint64_t next() {                                      // genrand64_int64
+    static const uint64_t mag01[2] = {0ull, 0xB5026F5AA96619E9ull};
+    const uint64_t UM = 0xFFFFFFFF80000000ull, LM = 0x7FFFFFFFull;
+    if (mti >= NN) {
+      int i;
+      uint64_t x;
+      for (i = 0; i < NN - MM; ++i) {
+        x = (mt[i] & UM) | (mt[i + 1] & LM);
+        mt[i] = mt[i + MM] ^ (x >> 1) ^ mag01[(int)(x & 1ull)];
+      }
+      for (; i < NN - 1; ++i) {
+        x = (mt[i] & UM) | (mt[i + 1] & LM);
+        mt[i] = mt[i + (MM - NN)] ^ (x >> 1) ^ mag01[(int)(x & 1ull)];
+      }
+      x = (mt[NN - 1] & UM) | (mt[0] & LM);
+      mt[NN - 1] = mt[MM - 1] ^ (x >> 1) ^ mag01[(int)(x & 1ull)];
+      mti = 0;
+    }
+    uint64_t x = mt[mti++];
+    x ^= (x >> 29) & 0x5555555555555555ull;
+    x ^= (x << 17) & 0x71D67FFFEDA60000ull;
+    x ^= (x << 37) & 0xFFF7EEE000000000ull;
+    x ^= (x >> 43);
+    return x;
+  }
+};
+}  // namespace
+
+int rth_mt19937_64(uint64_t seed, int32_t n, uint64_t *out) {
+  if (n < 0 || !out) return RT_ERR_INVALID;
+  PureMT64 g(seed);
+  for (int i = 0; i < n; ++i) out[i] = g.next();
+  return RT_OK;
+}
+
+int rth_generate_grids_pure64(uint64_t seed, int32_t n_grids, int32_t aa, float *out) {
+  if (n_grids <= 0 || aa <= 0 || aa > 64 || !out) return RT_ERR_INVALID;
+  const int nn = aa * aa;
+  // every draw of the run comes from ONE stream: word i is what the generator reached after i steps
+  const size_t n_words = std::max((size_t)2 * nn * n_grids, (size_t)n_grids + nn);
+  std::vector<uint64_t> w(n_words);
+  PureMT64 g(seed);
+  for (uint64_t &x : w) x = g.next();
+  std::vector<float> px(nn), py(nn);
+  std::vector<int> remaining, perm(nn);
+  const float nf = (float)aa;
+  for (int k = 0; k < n_grids; ++k) {
+    // randomFloats (:478-481): double2Float (fromIntegral (w `div` 2048) / 9007199254740992)
+    const uint64_t *f = &w[(size_t)2 * nn * k];
+    auto rf = [&](int i) { return (float)((double)(f[i] >> 11) / 9007199254740992.0); };
+    for (int p = 0; p < aa; ++p)                        // getGridR (:215-222), cells p-major
+      for (int q = 0; q < aa; ++q) {
+        const int c = p * aa + q;
+        px[c] = ((float)p + rf(c)) / nf;
+        py[c] = ((float)q + rf(nn + c)) / nf;
+      }
+    // shuffle' xs nn gen_k: r_j = (x_j - minBound) mod (nn - j + 1), x_j = the j-th word from position k on;
+    // output element j-1 = the r_j-th of what remains; the last remaining element closes the list
+    remaining.resize(nn);
+    for (int i = 0; i < nn; ++i) remaining[i] = i;
+    for (int j = 1; j < nn; ++j) {
+      const uint64_t x = w[(size_t)k + (j - 1)] ^ 0x8000000000000000ull;   // Int x - minBound, as an unsigned number
+      const int r = (int)(x % (uint64_t)(nn - j + 1));
+      perm[j - 1] = remaining[r];
+      remaining.erase(remaining.begin() + r);
+    }
+    perm[nn - 1] = remaining[0];
+    // dof = shuffle' aa .. gen, ss = shuffle' dof .. gen with the same gen (:471-475): position i of
+    // dof holds aa[perm[i]], position i of ss holds dof[perm[i]] = aa[perm[perm[i]]]
+    float *o = out + (size_t)k * nn * 6;
+    for (int i = 0; i < nn; ++i) {
+      const int d = perm[i], s2 = perm[perm[i]];
+      o[i * 6 + 0] = px[i];
+      o[i * 6 + 1] = py[i];
+      o[i * 6 + 2] = px[d];
+      o[i * 6 + 3] = py[d];
+      o[i * 6 + 4] = px[s2];
+      o[i * 6 + 5] = py[s2];
+    }
+  }
+  return RT_OK;
+}
+
 // clamp (Main.hs:99-101) then truncate (255*)
 static inline uint8_t quant(float x) {
   float c = (x < 0) ? 0.0f : ((x > 1) ? 1.0f : x);

@@ -160,46 +160,60 @@ int fail(rt_ctx *c, int code, const char *fmt, ...) {
                   __LINE__);                                                                 \
   } while (0)
 
-// Host -> device copy of one of the context's input tables.  The allocation is kept while it
-// is large enough (an animation uploads a same-sized scene every frame), and the copy is
-// ordered on the CONTEXT's stream and waited for there: it cannot overtake the context's frame
-// in flight, which still reads the old table, and it does not stall the other contexts of
-// the GPU the way hipFree / a null-stream copy (device-wide synchronisation) would.
-template <class T>
-int upload(rt_ctx *c, T **dst, size_t *cap, const void *src, size_t bytes) {
-  if (bytes == 0) bytes = 16;
-  if (!*dst || *cap < bytes) {
-    if (*dst) {
-      (void)hipFree(*dst);
-      *dst = nullptr;
-      *cap = 0;
-    }
-    // (with headroom: an animated scene's tree changes shape from frame to frame, and growing by
-    //  a few records must not mean a hipFree -- a device-wide wait of tens of milliseconds)
-    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
-    HIP_TRY(c, hipMalloc((void **)dst, want));
-    *cap = want;
+// Host -> device copies of the context's input tables, batched: every table of one call goes
+// through the context's pinned staging buffer and is copied on the CONTEXT's stream, which is
+// waited for ONCE (an animation uploads five tables per frame).  The allocations are kept while
+// they are large enough, with headroom (an animated scene's tree changes shape from frame to
+// frame; growing by a few records must not mean a hipFree -- a device-wide wait of tens of
+// milliseconds).  Ordered on the context's stream, the copies cannot overtake the context's frame
+// in flight, which still reads the old tables, and do not stall the other contexts of the GPU the
+// way a null-stream copy (device-wide synchronisation) would.
+struct UploadBatch {
+  struct Item { void **dst; size_t *cap; const void *src; size_t bytes; };
+  std::vector<Item> items;
+  template <class T>
+  void add(T **dst, size_t *cap, const void *src, size_t bytes) {
+    items.push_back({reinterpret_cast<void **>(dst), cap, bytes ? src : nullptr, bytes ? bytes : 16});  // (empty table: allocate, copy nothing)
   }
-  if (src) {
+  int run(rt_ctx *c) {
+    size_t total = 0;
+    for (Item &it : items) {
+      if (!*it.dst || *it.cap < it.bytes) {
+        if (*it.dst) {
+          (void)hipFree(*it.dst);
+          *it.dst = nullptr;
+          *it.cap = 0;
+        }
+        const size_t want = std::max<size_t>(it.bytes + it.bytes / 2, 4096);
+        HIP_TRY(c, hipMalloc(it.dst, want));
+        *it.cap = want;
+      }
+      if (it.src) total += (it.bytes + 255) & ~(size_t)255;
+    }
+    if (!total) return RT_OK;
     // a frame enqueued on a caller's stream is not ordered before c->stream: wait for it first
     if (c->last_launch_stream && c->last_launch_stream != c->stream)
       HIP_TRY(c, hipStreamSynchronize(c->last_launch_stream));
-    // through the context's own pinned staging buffer, so that the copy is a plain DMA on this
-    // stream and never depends on how the runtime stages pageable memory
-    if (c->stage_cap < bytes) {
+    if (c->stage_cap < total) {
       if (c->h_stage) (void)hipHostFree(c->h_stage);
       c->h_stage = nullptr;
       c->stage_cap = 0;
-      size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+      size_t cap = std::max<size_t>(total * 2, 1 << 16);
       HIP_TRY(c, hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
       c->stage_cap = cap;
     }
-    std::memcpy(c->h_stage, src, bytes);
-    HIP_TRY(c, hipMemcpyAsync(*dst, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    size_t off = 0;
+    for (Item &it : items) {
+      if (!it.src) continue;
+      char *stage = static_cast<char *>(c->h_stage) + off;
+      std::memcpy(stage, it.src, it.bytes);
+      HIP_TRY(c, hipMemcpyAsync(*it.dst, stage, it.bytes, hipMemcpyHostToDevice, c->stream));
+      off += (it.bytes + 255) & ~(size_t)255;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
+    return RT_OK;
   }
-  return RT_OK;
-}
+};
 
 void compute_tiling(rt_ctx *c) {
   // ~1024 samples per tile, power-of-two sides, width >= height (mirrored by
@@ -809,21 +823,23 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if (rp.max_depth > 64)
     return fail(c, RT_ERR_LIMIT, "BVH depth %d exceeds the traversal stack limit of 64", rp.max_depth);
   int rc;
-  if ((rc = upload(c, &c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4))) return rc;
-  if ((rc = upload(c, &c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4))) return rc;
+  UploadBatch up;
+  up.add(&c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4);
+  up.add(&c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4);
   WideBuild wb{rp.nodes};
   wb.cap = std::max(27, rp.max_depth);
   wb.height.assign(rp.nodes.size() / 16, -1);
   if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
   else wb.wide.assign(32, 0.0f), std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
-  if ((rc = upload(c, &c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4))) return rc;
+  up.add(&c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4);
   c->n_wnode_recs = (int)(wb.wide.size() / 32);
   c->wide_stack = wb.max_stack;
   if (std::getenv("RT_DEBUG_UPLOAD"))
     std::fprintf(stderr, "[rt_upload_scene] binary records %zu (depth %d), wide records %d, wide stack need %d (cap %d), primitives %zu\n",
                  rp.nodes.size() / 16, rp.max_depth, c->n_wnode_recs, wb.max_stack, wb.cap, rp.prims.size() / 16);
-  if ((rc = upload(c, &c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material)))) return rc;
-  if ((rc = upload(c, &c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light)))) return rc;
+  up.add(&c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material));
+  up.add(&c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light));
+  if ((rc = up.run(c))) return rc;
   c->n_lights = sc->n_lights;
   c->n_materials = sc->n_materials;
   c->n_node_recs = (int)(rp.nodes.size() / 16);
@@ -862,7 +878,9 @@ int rt_set_samples(rt_ctx *c, const float *f6, int32_t n_grids, int32_t spp) {
   if (!c || !f6) return RT_ERR_INVALID;
   if (n_grids < 1 || spp < 1 || spp > 1024) return fail(c, RT_ERR_INVALID, "bad sample table shape");
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = upload(c, &c->d_f6, &c->cap_f6, f6, (size_t)n_grids * spp * 6 * sizeof(float));
+  UploadBatch up;
+  up.add(&c->d_f6, &c->cap_f6, f6, (size_t)n_grids * spp * 6 * sizeof(float));
+  int rc = up.run(c);
   if (rc) return rc;
   c->n_grids = n_grids;
   c->spp = spp;

@@ -283,3 +283,54 @@ def test_sah_split_by_hand_with_the_surface_area_quirk(rt):
     # (splitAt on the list re-sorted along the best axis, :47)
     tree, _ = _tree(_x_spheres(rt, [2, -5, -12, -11]))
     assert tree == ([2, 3, 1], [0])
+
+
+# --- seed-level generateGrids (PARITY UNPINNED: the three packages are not in the reference) ---
+def test_mt19937_64_known_answers(rt):
+    """MT19937-64 as published (mt19937-64.c): with init_genrand64(5489) the first word is
+    14514284786278117030 and the 10000th 9981545732273789042 (the value ISO C++ [rand.predef]
+    requires of mt19937_64)."""
+    w = rt.mt19937_64(5489, 10000)
+    assert int(w[0]) == 14514284786278117030 and int(w[9999]) == 9981545732273789042
+
+
+def test_generate_grids_pure64_follows_the_call_sites(rt):
+    """generateGrids / getGrids / getGridR / randomFloats (RayTracer.hs:462-481, 215-222) with the
+    package algorithms named in include/rt_host.h, re-derived here in plain Python integers:
+    grid k takes floats 2*aa^2*k.. of the stream and shuffles with the stream entered k words in."""
+    seed, num, aa = 20150314, 7, 3
+    nn = aa * aa
+    g = rt.generate_grids_pure64(seed, num, aa)
+    w = [int(x) for x in rt.mt19937_64(seed, 2 * nn * num + nn)]
+    f32 = np.float32
+    for k in range(num):
+        fl = [f32((w[2 * nn * k + i] >> 11) / 9007199254740992.0) for i in range(2 * nn)]   # double2Float . randomDouble
+        cells = [(p, q) for p in range(aa) for q in range(aa)]
+        pts = [((f32(p) + fl[c]) / f32(aa), (f32(q) + fl[nn + c]) / f32(aa)) for c, (p, q) in enumerate(cells)]
+        # shuffle' xs nn gen_k: r_j = randomR (0, nn - j), one 64-bit draw each, (x - minBound) mod (nn - j + 1)
+        rs = [((w[k + j - 1] ^ (1 << 63)) % (nn - j + 1)) for j in range(1, nn)]
+
+        def shuffle(xs):
+            rem, out = list(xs), []
+            for r in rs:
+                out.append(rem.pop(r))
+            return out + rem
+        dof = shuffle(pts)
+        ss = shuffle(dof)
+        for i in range(nn):
+            exp = [pts[i][0], pts[i][1], dof[i][0], dof[i][1], ss[i][0], ss[i][1]]
+            assert [float(x) for x in g[k, i]] == [float(x) for x in exp], (k, i)
+    # stratification: sample c of every grid lies in cell (c // aa, c % aa)
+    cell = np.floor(g[:, :, 0:2] * aa).astype(int)
+    assert (cell[:, :, 0] == np.arange(nn)[None, :] // aa).all() and (cell[:, :, 1] == np.arange(nn)[None, :] % aa).all()
+    # aa = 1: the three pairs are one point (RayTracer.hs:471-475 with a one-element list)
+    g1 = rt.generate_grids_pure64(seed, 5, 1)
+    assert (g1[:, 0, 0:2] == g1[:, 0, 2:4]).all() and (g1[:, 0, 0:2] == g1[:, 0, 4:6]).all()
+
+
+def test_oracle_renders_with_the_seed_level_table(rt, oracle):
+    from conftest import make_world
+    w = make_world(rt, "bench1", 48, 32, 4)
+    a, _, st = oracle.render(w, rt.generate_grids_pure64(7, 58, 2), oracle.FLAG_CULL_ZERO_WEIGHT)
+    b, _, _ = oracle.render(w, rt.generate_grids_pure64(8, 58, 2), oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert np.isfinite(a).all() and st.rays_primary == 48 * 32 * 4 and not np.array_equal(a, b)
