@@ -156,6 +156,10 @@ def main() -> None:
                     help="N > 1: 'tiles' = every frame split over the ranks + RCCL gather (default); 'frames' "
                          "(animation, SURVEY 8e / config 5) = rank r renders whole frames r, r+N, ... with no "
                          "data-path collective")
+    ap.add_argument("--rebuild-every", type=int, default=1, metavar="K",
+                    help="animation (c5): a context rebuilds sahBVH on the host and uploads only for every K-th of "
+                         "its frames and refits the boxes on the GPU in between (rt_refit_async); 1 = rebuild "
+                         "every frame, as the reference's host would")
     ap.add_argument("--rehearse-share", default=None, metavar="R/N",
                     help="one-GPU timing rehearsal of rank R's share of an N-rank job (no collective); "
                          "the line then reports that share's rays only")
@@ -206,12 +210,17 @@ def main() -> None:
     animated = WORKLOADS[args.workload][1] is None
     frame_no = [0]
 
+    per_context = {}
+
     def submit():
         if animated:
             frame_no[0] += 1
             # frame index: this rank's own sequence, or every world_size-th frame of the job's
             k = frame_no[0] * world_size + rank if by_frames else frame_no[0]
-            df.submit(args.flags, make_world(args.workload, float(k)))
+            slot = df.k % df.depth
+            n = per_context.get(slot, 0)
+            per_context[slot] = n + 1
+            df.submit(args.flags, make_world(args.workload, float(k)), refit=(n % max(1, args.rebuild_every)) != 0)
         else:
             df.submit(args.flags)
 
@@ -265,6 +274,9 @@ def main() -> None:
         }
         if args.rehearse_share:
             out["config"]["rehearsal_of_rank_share"] = args.rehearse_share
+        if animated:
+            out["config"]["bvh_per_frame"] = ("sahBVH rebuilt on the host + upload every frame" if args.rebuild_every <= 1 else
+                                              f"rebuilt + uploaded every {args.rebuild_every} frames of a context, boxes refitted on the GPU in between")
         if by_frames:
             # a step = one frame on EVERY rank (world_size frames); per-GPU work is fixed as N grows
             out["scaling"] = "weak"

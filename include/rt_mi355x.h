@@ -177,6 +177,21 @@ void rt_shutdown(rt_ctx *ctx);
  * replaces the in-memory `World` fields of src/Types.hs:142-144. */
 int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
 
+/* Animation (BASELINE config 5): the objects of the uploaded scene have MOVED --
+ * same counts, same order in the arrays, same materials -- and the tree keeps the topology of the
+ * last rt_upload_scene.  Every box is refitted bottom-up ON THE GPU: toBox per object, a leaf's box
+ * = left fold of `surround` over its objects, a node's = `surround` of its children's
+ * (BoundingVolumeHierarchy.hs:50-51,135-142,178-189; Haskell's min/max), i.e. exactly the boxes
+ * sahBVH would attach to this topology; the primitive records and the wide records follow.  No
+ * host rebuild, one staged copy of the two object arrays.  This is a TREE-CHANGING mode with
+ * respect to a host that rebuilds sahBVH every frame: closest hits are the same, but among
+ * objects hit at EQUAL distance the winner follows the stale topology's leaf order
+ * (src/RayTracer.hs:383-402,410).  Rebuild (rt_upload_scene) every few frames to keep the tree
+ * tight.  Enqueued on the context's own stream (hip_stream must be NULL), behind its frame in
+ * flight; host arrays are copied before the call returns. */
+int rt_refit_async(rt_ctx *ctx, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                   int32_t n_triangles, void *hip_stream);
+
 /* The remaining World fields (src/Types.hs:132-141,143,145). */
 int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 
@@ -301,6 +316,8 @@ typedef struct rt_multi rt_multi;
 int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out);
 void rt_multi_shutdown(rt_multi *m);
 int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene);
+int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                   int32_t n_triangles);   /* rt_refit_async on every GPU */
 int rt_multi_set_camera(rt_multi *m, const rt_camera *cam);
 int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t spp);
 /* render on all GPUs (blocking).  rgb_out: img_w*img_h*3 floats as rt_render, or NULL;

@@ -116,7 +116,7 @@ DEVICE_SYMBOLS = [
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
     "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing", "rt_render_static_async",
     "rt_assemble8_async", "rt_multi_init", "rt_multi_shutdown", "rt_multi_upload_scene", "rt_multi_set_camera",
-    "rt_multi_set_samples", "rt_multi_render", "rt_multi_last_error",
+    "rt_multi_set_samples", "rt_multi_render", "rt_multi_last_error", "rt_refit_async", "rt_multi_refit",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -217,6 +217,7 @@ def device_lib() -> C.CDLL:
         L.rt_shutdown.restype = None
         L.rt_upload_scene.argtypes = [vp, C.POINTER(SceneView)]
         L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.rt_refit_async.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32, vp]
         L.rt_set_samples.argtypes = [vp, C.POINTER(f32), i32, i32]
         L.rt_set_partition.argtypes = [vp, i32, i32]
         L.rt_get_tiling.argtypes = [vp, C.POINTER(Tiling)]
@@ -233,6 +234,7 @@ def device_lib() -> C.CDLL:
         L.rt_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
         L.rt_multi_set_samples.argtypes = [vp, C.POINTER(f32), i32, i32]
         L.rt_multi_render.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(C.c_uint8), C.POINTER(Stats)]
+        L.rt_multi_refit.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32]
         L.rt_multi_last_error.argtypes = [vp]
         L.rt_multi_last_error.restype = C.c_char_p
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
@@ -494,6 +496,13 @@ class Renderer:
         self._check(self.lib.rt_set_camera(self._h, C.byref(world.camera)), "rt_set_camera")
         self.world = world
 
+    def refit(self, scene: "Scene") -> None:
+        """rt_refit_async: the uploaded scene's objects moved to `scene`'s positions (same counts
+        and order); boxes refitted on the GPU, the tree's topology kept."""
+        v = scene.view
+        self._check(self.lib.rt_refit_async(self._h, v.spheres, v.n_spheres, v.triangles, v.n_triangles, None),
+                    "rt_refit_async")
+
     def set_samples(self, grids: np.ndarray) -> None:
         g = np.ascontiguousarray(grids, np.float32)
         assert g.ndim == 3 and g.shape[2] == 6
@@ -612,6 +621,10 @@ class MultiRenderer:
         g = np.ascontiguousarray(grids, np.float32)
         self._check(self.lib.rt_multi_set_samples(self._h, g.ctypes.data_as(C.POINTER(f32)), g.shape[0],
                                                   g.shape[1]), "rt_multi_set_samples")
+
+    def refit(self, scene: "Scene") -> None:
+        v = scene.view
+        self._check(self.lib.rt_multi_refit(self._h, v.spheres, v.n_spheres, v.triangles, v.n_triangles), "rt_multi_refit")
 
     def render(self, flags: int = 0, want_float: bool = True, want_8bit: bool = False):
         """Returns (rgb [H*W,3] f32 or None, rgb8 [H*W,3] u8 or None, Stats)."""

@@ -276,12 +276,19 @@ def parse_scene_description(text: str) -> SceneDescription:
 
 
 def render_sequence(renderer, description: SceneDescription, config: Config, grids, frames,
-                    flags: int = 0):
+                    flags: int = 0, rebuild_every: int = 1):
     """The animation loop: for every frame number, re-evaluate the shapes, rebuild the BVH on
-    the host, upload, render.  Yields (t, rgb [H*W,3] float32, Stats)."""
+    the host (sahBVH), upload, render.  Yields (t, rgb [H*W,3] float32, Stats).
+    rebuild_every = k > 1: only every k-th frame is rebuilt and uploaded; the frames between keep
+    that tree's topology and have their boxes refitted on the GPU (rt_refit_async) -- a
+    tree-changing mode: same closest hits, ties between coincident surfaces follow the stale
+    tree's leaf order."""
     renderer.set_samples(grids)
-    for t in frames:
-        renderer.set_world(description.world_at(t, config))
+    for k, t in enumerate(frames):
+        if k % max(1, rebuild_every) == 0:
+            renderer.set_world(description.world_at(t, config))
+        else:
+            renderer.refit(description.scene_at(t))
         rgb, _, st = renderer.render(flags)
         yield t, rgb, st
 

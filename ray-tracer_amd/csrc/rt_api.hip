@@ -36,6 +36,19 @@ struct rt_ctx {
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   int n_wnode_recs = 0, wide_stack = 0;  // wide records; most stack entries a wide traversal can hold at once
+  // refit (rt_refit_async): which object a primitive record came from, which binary record and side a
+  // wide slot copies, and the binary records bottom-up by depth; kept on the host by rt_upload_scene,
+  // uploaded by the first refit after it
+  std::vector<uint32_t> h_prim_src;
+  std::vector<int> h_wide_src, h_level_nodes, h_level_start;
+  int n_spheres = 0, n_triangles = 0;
+  bool refit_ready = false;
+  uint32_t *d_prim_src = nullptr;
+  int *d_wide_src = nullptr, *d_level_nodes = nullptr;
+  float *d_prim_box = nullptr;
+  rt_sphere *d_spheres = nullptr;
+  rt_triangle *d_triangles = nullptr;
+  size_t cap_prim_src = 0, cap_wide_src = 0, cap_level_nodes = 0, cap_prim_box = 0, cap_spheres = 0, cap_triangles = 0;
   int lds_scene_mode = -1;  // RT_LDS_SCENE: 0 never, 1/-1 when it fits (tuning knob)
   int five_waves_mode = -1; // RT_FIVE_WAVES: 0 never use the 96-VGPR build
   bool have_scene = false;
@@ -236,6 +249,7 @@ struct Repack {
   std::vector<float> nodes;  // 16 floats per device node
   std::vector<float> prims;  // 16 floats per record
   std::vector<char> seen;
+  std::vector<uint32_t> prim_src;  // leaf_refs entry each primitive record was made from
   int max_depth = 0;
   std::string err;
 
@@ -273,6 +287,7 @@ struct Repack {
       }
       put_i(rec + 15, 0);
       prims.insert(prims.end(), rec, rec + 16);
+      prim_src.push_back(r);
     }
     put_i(&prims[(size_t)first_rec * 16 + 15], count);
     return -1 - first_rec;
@@ -324,6 +339,7 @@ struct Repack {
 struct WideBuild {
   const std::vector<float> &bin;  // 16 floats per binary record
   std::vector<float> wide;        // 32 floats per wide record
+  std::vector<int> src;           // per wide slot: (binary record << 1) | side whose box it copies, -1 = none
   int max_stack = 0;
   // Most entries the traversal stack may ever hold.  A wide node leaves up to 3 siblings on the
   // stack per level instead of the binary tree's 1, and the per-lane stacks are LDS: 27 entries
@@ -344,7 +360,7 @@ struct WideBuild {
     return height[bidx] = h;
   }
 
-  struct Child { float box[6]; int ref; };
+  struct Child { float box[6]; int ref; int from; };
   static int get_i(const float *p) { int v; std::memcpy(&v, p, 4); return v; }
   static float area(const float *b) {
     float w = b[1] - b[0], h = b[3] - b[2], d = b[5] - b[4];
@@ -358,6 +374,7 @@ struct WideBuild {
       Child c;
       std::memcpy(c.box, r + 6 * k, 24);
       c.ref = ref;
+      c.from = (bidx << 1) | k;
       out.push_back(c);
     }
   }
@@ -388,6 +405,7 @@ struct WideBuild {
     }
     const int me = (int)(wide.size() / 32);
     wide.resize(wide.size() + 32, 0.0f);
+    src.resize(src.size() + 4, -1);
     const int k = (int)ch.size();
     // entering a child leaves at most k - 1 siblings on the stack
     if (stack_above + k - 1 > max_stack) max_stack = stack_above + k - 1;
@@ -399,10 +417,94 @@ struct WideBuild {
       const Child &c = ch[i < k ? i : 0];
       for (int pl = 0; pl < 6; ++pl) w[pl * 4 + i] = c.box[pl];
       std::memcpy(w + 24 + i, &refs[i], 4);
+      src[(size_t)me * 4 + i] = c.from;   // (an absent child copies child 0's box, also on refit)
     }
     return me;
   }
 };
+
+// ---- refit (rt_refit_async): boxes of an unchanged tree from moved objects, on the GPU ----------
+// toBox (BoundingVolumeHierarchy.hs:178-189), surround (:135-142) with Haskell's min / max
+// (min x y = if x <= y then x else y), minimum / maximum = left folds.
+__device__ inline float hmin_d(float x, float y) { return x <= y ? x : y; }
+__device__ inline float hmax_d(float x, float y) { return x <= y ? y : x; }
+
+// one thread per primitive record: the record's geometry (as Repack::emit_leaf packs it) and its toBox
+__global__ void refit_prims_kernel(float *__restrict__ prims, const uint32_t *__restrict__ prim_src,
+                                   const rt_sphere *__restrict__ sph, const rt_triangle *__restrict__ tri,
+                                   float *__restrict__ prim_box, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float *rec = prims + (size_t)i * 16;
+  float *bx = prim_box + (size_t)i * 6;
+  const uint32_t r = prim_src[i];
+  if (r & RT_REF_TRIANGLE) {
+    const rt_triangle t = tri[RT_REF_INDEX(r)];
+    for (int a = 0; a < 3; ++a) {
+      rec[0 + a] = t.a[a];
+      rec[3 + a] = t.a[a] - t.b[a];
+      rec[6 + a] = t.a[a] - t.c[a];
+      rec[9 + a] = t.n[a];
+      bx[2 * a] = hmin_d(hmin_d(t.a[a], t.b[a]), t.c[a]);
+      bx[2 * a + 1] = hmax_d(hmax_d(t.a[a], t.b[a]), t.c[a]);
+    }
+  } else {
+    const rt_sphere p = sph[r];
+    for (int a = 0; a < 3; ++a) {
+      rec[a] = p.center[a];
+      bx[2 * a] = p.center[a] - p.radius;
+      bx[2 * a + 1] = p.center[a] + p.radius;
+    }
+    rec[3] = p.radius;
+    rec[4] = p.radius * p.radius;
+  }
+}
+
+// one thread per (binary record of one depth level, side): the child's box -- a leaf's is the left
+// fold of its objects' boxes in LIST order (records are stored reversed), an inner node's the
+// union of the two boxes its own record holds (already refitted: deeper levels run first)
+__global__ void refit_nodes_kernel(float *__restrict__ nodes, const float *__restrict__ prims,
+                                   const float *__restrict__ prim_box, const int *__restrict__ level_nodes, int lo,
+                                   int hi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 2 * (hi - lo)) return;
+  const int rec = level_nodes[lo + (k >> 1)], side = k & 1;
+  float *me = nodes + (size_t)rec * 16;
+  const int ref = __float_as_int(me[12 + side]);
+  if (ref == REF_NONE) return;
+  float b[6];
+  if (ref < 0) {
+    const int first = -1 - ref, count = __float_as_int(prims[(size_t)first * 16 + 15]);
+    const float *p = prim_box + (size_t)(first + count - 1) * 6;
+    for (int a = 0; a < 6; ++a) b[a] = p[a];
+    for (int j = count - 2; j >= 0; --j) {
+      p = prim_box + (size_t)(first + j) * 6;
+      for (int a = 0; a < 3; ++a) {
+        b[2 * a] = hmin_d(b[2 * a], p[2 * a]);
+        b[2 * a + 1] = hmax_d(b[2 * a + 1], p[2 * a + 1]);
+      }
+    }
+  } else {
+    const float *ch = nodes + (size_t)ref * 16;
+    for (int a = 0; a < 3; ++a) {
+      b[2 * a] = hmin_d(ch[2 * a], ch[6 + 2 * a]);
+      b[2 * a + 1] = hmax_d(ch[2 * a + 1], ch[6 + 2 * a + 1]);
+    }
+  }
+  for (int a = 0; a < 6; ++a) me[6 * side + a] = b[a];
+}
+
+// one thread per wide slot: the box of the binary (record, side) it was collapsed from
+__global__ void refit_wide_kernel(float *__restrict__ wide, const float *__restrict__ nodes,
+                                  const int *__restrict__ wide_src, int n_slots) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  const int from = wide_src[k];
+  if (from < 0) return;
+  const float *b = nodes + (size_t)(from >> 1) * 16 + 6 * (from & 1);
+  float *w = wide + (size_t)(k >> 2) * 32 + (k & 3);
+  for (int pl = 0; pl < 6; ++pl) w[pl * 4] = b[pl];
+}
 
 template <class T>
 __global__ void assemble_kernel(const T *__restrict__ gathered, int nranks, size_t stride,
@@ -777,7 +879,8 @@ void rt_shutdown(rt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
+                  c->d_spheres, c->d_triangles, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
@@ -834,6 +937,32 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   up.add(&c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4);
   c->n_wnode_recs = (int)(wb.wide.size() / 32);
   c->wide_stack = wb.max_stack;
+  // refit tables (host copies; uploaded by the first rt_refit_async)
+  c->h_prim_src.swap(rp.prim_src);
+  c->h_wide_src.swap(wb.src);
+  for (int i = 0; i < 4; ++i)   // absent children copy child 0's box
+    for (size_t wn = 0; wn < c->h_wide_src.size() / 4; ++wn)
+      if (c->h_wide_src[wn * 4 + i] < 0) c->h_wide_src[wn * 4 + i] = c->h_wide_src[wn * 4];
+  {
+    const int nb = (int)(rp.nodes.size() / 16);
+    std::vector<int> depth(nb, 0);
+    int deepest = 0;
+    for (int i = 0; i < nb; ++i)   // records are in pre-order: a parent comes before its children
+      for (int k = 0; k < 2; ++k) {
+        int ref = WideBuild::get_i(&rp.nodes[(size_t)i * 16 + 12 + k]);
+        if (ref >= 0 && ref != i) { depth[ref] = depth[i] + 1; deepest = std::max(deepest, depth[ref]); }
+      }
+    c->h_level_nodes.clear();
+    c->h_level_start.assign(1, 0);
+    for (int d = deepest; d >= 0; --d) {   // deepest level first
+      for (int i = 0; i < nb; ++i)
+        if (depth[i] == d) c->h_level_nodes.push_back(i);
+      c->h_level_start.push_back((int)c->h_level_nodes.size());
+    }
+  }
+  c->n_spheres = sc->n_spheres;
+  c->n_triangles = sc->n_triangles;
+  c->refit_ready = false;
   if (std::getenv("RT_DEBUG_UPLOAD"))
     std::fprintf(stderr, "[rt_upload_scene] binary records %zu (depth %d), wide records %d, wide stack need %d (cap %d), primitives %zu\n",
                  rp.nodes.size() / 16, rp.max_depth, c->n_wnode_recs, wb.max_stack, wb.cap, rp.prims.size() / 16);
@@ -886,6 +1015,65 @@ int rt_set_samples(rt_ctx *c, const float *f6, int32_t n_grids, int32_t spp) {
   c->spp = spp;
   c->have_samples = true;
   c->prepared = false;
+  return RT_OK;
+}
+
+int rt_refit_async(rt_ctx *c, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                   int32_t n_triangles, void *stream) {
+  if (!c) return RT_ERR_INVALID;
+  if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_upload_scene has not been called");
+  if (n_spheres != c->n_spheres || n_triangles != c->n_triangles)
+    return fail(c, RT_ERR_INVALID, "rt_refit_async: %d spheres / %d triangles, the uploaded scene has %d / %d", n_spheres,
+                n_triangles, c->n_spheres, c->n_triangles);
+  if ((n_spheres && !spheres) || (n_triangles && !triangles)) return fail(c, RT_ERR_INVALID, "null object array");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (s != c->stream) return fail(c, RT_ERR_INVALID, "rt_refit_async runs on the context's own stream (pass NULL)");
+  const int n_prims = c->n_prim_recs, n_bin = c->n_node_recs;
+  UploadBatch up;
+  if (!c->refit_ready) {
+    up.add(&c->d_prim_src, &c->cap_prim_src, c->h_prim_src.data(), c->h_prim_src.size() * sizeof(uint32_t));
+    up.add(&c->d_wide_src, &c->cap_wide_src, c->h_wide_src.data(), c->h_wide_src.size() * sizeof(int));
+    up.add(&c->d_level_nodes, &c->cap_level_nodes, c->h_level_nodes.data(), c->h_level_nodes.size() * sizeof(int));
+    up.add(&c->d_prim_box, &c->cap_prim_box, nullptr, (size_t)std::max(1, n_prims) * 6 * sizeof(float));
+  }
+  up.add(&c->d_spheres, &c->cap_spheres, spheres, (size_t)n_spheres * sizeof(rt_sphere));
+  up.add(&c->d_triangles, &c->cap_triangles, triangles, (size_t)n_triangles * sizeof(rt_triangle));
+  int rc = up.run(c);   // ordered on the context's stream, behind its frame in flight
+  if (rc) return rc;
+  c->refit_ready = true;
+  (void)hipGetLastError();
+  if (n_prims > 0) {
+    hipLaunchKernelGGL(refit_prims_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, s, reinterpret_cast<float *>(c->d_prims),
+                       c->d_prim_src, c->d_spheres, c->d_triangles, c->d_prim_box, n_prims);
+    for (size_t lv = 0; lv + 1 < c->h_level_start.size(); ++lv) {
+      const int lo = c->h_level_start[lv], hi = c->h_level_start[lv + 1];
+      if (hi > lo)
+        hipLaunchKernelGGL(refit_nodes_kernel, dim3((2 * (hi - lo) + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<float *>(c->d_nodes), reinterpret_cast<const float *>(c->d_prims),
+                           c->d_prim_box, c->d_level_nodes, lo, hi);
+    }
+    const int n_slots = c->n_wnode_recs * 4;
+    hipLaunchKernelGGL(refit_wide_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, reinterpret_cast<float *>(c->d_wnodes),
+                       reinterpret_cast<const float *>(c->d_nodes), c->d_wide_src, n_slots);
+    HIP_TRY(c, hipGetLastError());
+  }
+  (void)n_bin;
+  // the exact-reciprocal box path needs every box coordinate 0 or in [2^-36, 2^59] and min <= max:
+  // box planes are object coordinates (triangles) or centre -+ radius (spheres)
+  c->boxes_safe = 1;
+  auto ok = [](float v) {
+    float a = std::fabs(v);
+    return v == 0.0f || (a >= 1.4551915228366852e-11f && a <= 5.764607523034235e17f);
+  };
+  for (int i = 0; i < n_triangles && c->boxes_safe; ++i)
+    for (int a = 0; a < 3; ++a)
+      if (!ok(triangles[i].a[a]) || !ok(triangles[i].b[a]) || !ok(triangles[i].c[a])) c->boxes_safe = 0;
+  for (int i = 0; i < n_spheres && c->boxes_safe; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float lo = spheres[i].center[a] - spheres[i].radius, hi = spheres[i].center[a] + spheres[i].radius;
+      if (!ok(lo) || !ok(hi) || !(lo <= hi)) c->boxes_safe = 0;
+    }
   return RT_OK;
 }
 

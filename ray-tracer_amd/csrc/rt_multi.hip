@@ -239,6 +239,14 @@ int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene) {
   return RT_OK;
 }
 
+int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                   int32_t n_triangles) {
+  if (!m) return RT_ERR_INVALID;
+  for (int r = 0; r < m->n; ++r)
+    M_CTX(m, r, rt_refit_async(m->ctx[r], spheres, n_spheres, triangles, n_triangles, nullptr));
+  return RT_OK;
+}
+
 int rt_multi_set_camera(rt_multi *m, const rt_camera *cam) {
   if (!m || !cam) return RT_ERR_INVALID;
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_camera(m->ctx[r], cam));

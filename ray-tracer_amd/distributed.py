@@ -164,14 +164,18 @@ class DistributedFrame:
         """The most recently submitted frame (valid after finish())."""
         return self.frames[(self.k - 1) % self.depth] if self.k else self.frames[0]
 
-    def submit(self, flags: int = 0, world=None) -> None:
+    def submit(self, flags: int = 0, world=None, refit: bool = False) -> None:
         """Enqueue one frame; returns without waiting for the GPU.  `world` (animation): the
         frame's own World, uploaded to the frame's context first (rt_upload_scene frees the
-        previous scene, which waits for that context's frame in flight)."""
+        previous scene, which waits for that context's frame in flight); with `refit` the context
+        keeps its tree and only refits the boxes to the world's objects on the GPU (rt_refit_async)."""
         slot = self.k % self.depth
         rs, r = self.streams[slot], self.renderers[slot]
         if world is not None:
-            r.set_world(world)
+            if refit:
+                r.refit(world.scene)
+            else:
+                r.set_world(world)
         if not self.collective:
             if self.rehearsal:
                 r.render_tiles_async(self.frames[slot].data_ptr(), flags, rs.cuda_stream)
