@@ -28,9 +28,9 @@ struct rt_ctx {
   std::string err;
 
   // scene
-  float4 *d_nodes = nullptr, *d_prims = nullptr, *d_wnodes = nullptr;
+  float4 *d_nodes = nullptr, *d_prims = nullptr, *d_wnodes = nullptr, *d_leafbox = nullptr;
   float *d_materials = nullptr, *d_lights = nullptr;
-  size_t cap_nodes = 0, cap_prims = 0, cap_wnodes = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
+  size_t cap_nodes = 0, cap_prims = 0, cap_wnodes = 0, cap_leafbox = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
   void *h_stage = nullptr;  // pinned staging buffer of the uploads
   size_t stage_cap = 0;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
@@ -250,6 +250,7 @@ struct Repack {
   std::vector<float> prims;  // 16 floats per record
   std::vector<char> seen;
   std::vector<uint32_t> prim_src;  // leaf_refs entry each primitive record was made from
+  std::vector<float> leafbox;      // 8 floats per primitive record: the box of the record's leaf
   int max_depth = 0;
   std::string err;
 
@@ -290,6 +291,8 @@ struct Repack {
       prim_src.push_back(r);
     }
     put_i(&prims[(size_t)first_rec * 16 + 15], count);
+    leafbox.resize(prims.size() / 2, 0.0f);
+    for (int k = 0; k < count; ++k) std::memcpy(&leafbox[(size_t)(first_rec + k) * 8], &n.xmin, 24);
     return -1 - first_rec;
   }
 
@@ -361,6 +364,7 @@ struct WideBuild {
   }
 
   struct Child { float box[6]; int ref; int from; };
+  static constexpr float ABSENT_PLANE = 288230376151711744.0f;  // 2^58
   static int get_i(const float *p) { int v; std::memcpy(&v, p, 4); return v; }
   static float area(const float *b) {
     float w = b[1] - b[0], h = b[3] - b[2], d = b[5] - b[4];
@@ -414,10 +418,15 @@ struct WideBuild {
       refs[i] = ch[i].ref >= 0 ? build(ch[i].ref, stack_above + k - 1) : ch[i].ref;
     float *w = &wide[(size_t)me * 32];
     for (int i = 0; i < 4; ++i) {
-      const Child &c = ch[i < k ? i : 0];
-      for (int pl = 0; pl < 6; ++pl) w[pl * 4 + i] = c.box[pl];
+      if (i < k) {
+        for (int pl = 0; pl < 6; ++pl) w[pl * 4 + i] = ch[i].box[pl];
+        src[(size_t)me * 4 + i] = ch[i].from;
+      } else {
+        // no such child: an inverted box, which the conservative test never enters (rt_kernels.inl);
+        // refit leaves it alone (src = -1)
+        for (int pl = 0; pl < 6; ++pl) w[pl * 4 + i] = (pl & 1) ? -ABSENT_PLANE : ABSENT_PLANE;
+      }
       std::memcpy(w + 24 + i, &refs[i], 4);
-      src[(size_t)me * 4 + i] = c.from;   // (an absent child copies child 0's box, also on refit)
     }
     return me;
   }
@@ -464,8 +473,8 @@ __global__ void refit_prims_kernel(float *__restrict__ prims, const uint32_t *__
 // fold of its objects' boxes in LIST order (records are stored reversed), an inner node's the
 // union of the two boxes its own record holds (already refitted: deeper levels run first)
 __global__ void refit_nodes_kernel(float *__restrict__ nodes, const float *__restrict__ prims,
-                                   const float *__restrict__ prim_box, const int *__restrict__ level_nodes, int lo,
-                                   int hi) {
+                                   const float *__restrict__ prim_box, float *__restrict__ leafbox,
+                                   const int *__restrict__ level_nodes, int lo, int hi) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= 2 * (hi - lo)) return;
   const int rec = level_nodes[lo + (k >> 1)], side = k & 1;
@@ -484,6 +493,8 @@ __global__ void refit_nodes_kernel(float *__restrict__ nodes, const float *__res
         b[2 * a + 1] = hmax_d(b[2 * a + 1], p[2 * a + 1]);
       }
     }
+    for (int j = 0; j < count; ++j)   // the leaf's own box, with each of its records (exact verdicts)
+      for (int a = 0; a < 6; ++a) leafbox[(size_t)(first + j) * 8 + a] = b[a];
   } else {
     const float *ch = nodes + (size_t)ref * 16;
     for (int a = 0; a < 3; ++a) {
@@ -710,8 +721,10 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.n_prim_recs = c->n_prim_recs;
   p.n_materials = c->n_materials;
   p.lds_prim_base = prune ? c->n_wnode_recs * LDS_WNODE_F4 : c->n_node_recs * LDS_REC_F4;
-  cfg.lds_scene_bytes = ((size_t)p.lds_prim_base + (size_t)c->n_prim_recs * LDS_REC_F4) * 16 +
-                        (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
+  p.lds_leafbox_base = p.lds_prim_base + c->n_prim_recs * LDS_REC_F4;
+  p.lds_rec_f4 = p.lds_leafbox_base + (prune ? c->n_prim_recs * 2 : 0);  // leaf boxes: pruned traversal only
+  p.leafbox = c->d_leafbox;
+  cfg.lds_scene_bytes = (size_t)p.lds_rec_f4 * 16 + (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
   int wpb = WAVES_PER_BLOCK;
   if (!cfg.lds_scene && c->lds_scene_mode != 0 && !cfg.count && cfg.prune &&
@@ -879,7 +892,7 @@ void rt_shutdown(rt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_leafbox, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
                   c->d_spheres, c->d_triangles, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
@@ -933,16 +946,19 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   wb.cap = std::max(27, rp.max_depth);
   wb.height.assign(rp.nodes.size() / 16, -1);
   if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
-  else wb.wide.assign(32, 0.0f), std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
+  else {
+    wb.wide.assign(32, 0.0f);
+    for (int i = 0; i < 24; ++i) wb.wide[i] = ((i >> 2) & 1) ? -WideBuild::ABSENT_PLANE : WideBuild::ABSENT_PLANE;
+    std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
+  }
   up.add(&c->d_wnodes, &c->cap_wnodes, wb.wide.data(), wb.wide.size() * 4);
+  rp.leafbox.resize(rp.prims.size() / 2, 0.0f);
+  up.add(&c->d_leafbox, &c->cap_leafbox, rp.leafbox.data(), rp.leafbox.size() * 4);
   c->n_wnode_recs = (int)(wb.wide.size() / 32);
   c->wide_stack = wb.max_stack;
   // refit tables (host copies; uploaded by the first rt_refit_async)
   c->h_prim_src.swap(rp.prim_src);
   c->h_wide_src.swap(wb.src);
-  for (int i = 0; i < 4; ++i)   // absent children copy child 0's box
-    for (size_t wn = 0; wn < c->h_wide_src.size() / 4; ++wn)
-      if (c->h_wide_src[wn * 4 + i] < 0) c->h_wide_src[wn * 4 + i] = c->h_wide_src[wn * 4];
   {
     const int nb = (int)(rp.nodes.size() / 16);
     std::vector<int> depth(nb, 0);
@@ -1051,7 +1067,7 @@ int rt_refit_async(rt_ctx *c, const rt_sphere *spheres, int32_t n_spheres, const
       if (hi > lo)
         hipLaunchKernelGGL(refit_nodes_kernel, dim3((2 * (hi - lo) + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<float *>(c->d_nodes), reinterpret_cast<const float *>(c->d_prims),
-                           c->d_prim_box, c->d_level_nodes, lo, hi);
+                           c->d_prim_box, reinterpret_cast<float *>(c->d_leafbox), c->d_level_nodes, lo, hi);
     }
     const int n_slots = c->n_wnode_recs * 4;
     hipLaunchKernelGGL(refit_wide_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, reinterpret_cast<float *>(c->d_wnodes),

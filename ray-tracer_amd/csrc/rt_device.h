@@ -39,7 +39,7 @@ constexpr int PRIM_F4 = 4;
 // children until there are four).  One fetch decides four hitsBox tests and the dependent chain
 // pop -> fetch -> test -> descend is walked half as often.  Boxes are stored plane by plane,
 //   f4[0] xmin of the 4 children  f4[1] xmax   f4[2] ymin  f4[3] ymax   f4[4] zmin  f4[5] zmax
-//   f4[6] the 4 child refs (as in the binary record; REF_NONE = no such child, box = child 0's)
+//   f4[6] the 4 child refs (as in the binary record; REF_NONE = no such child, with an inverted box)
 // so that a ray whose direction sign on an axis is s reads its NEAR planes at f4[2a + s] and its
 // FAR planes at f4[2a + (s ^ 1)]: hitsBox's six sign selects per box (BoundingVolumeHierarchy.hs:
 // 194-199) become three per-ray address offsets.  Every primitive whose leaf box passes hitsBox is
@@ -95,6 +95,8 @@ struct RenderParams {
   int n_node_recs, n_prim_recs;          // device records (for the LDS scene copy)
   const float4 *wnodes;                  // wide node records (pruned traversal)
   int n_wnode_recs, lds_prim_base;       // lds_prim_base: float4 offset of the primitive records in the LDS scene copy
+  const float4 *leafbox;                 // 2 float4 per primitive record: the box of the record's leaf (exact verdicts)
+  int lds_leafbox_base, lds_rec_f4;      // float4 offset of the leaf boxes in the LDS copy; float4s of all its records
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
   FastDiv fd_groups_per_tile, fd_tiles_x, fd_spp, fd_tile_w, fd_n_grids;  // the hot loop's divisors

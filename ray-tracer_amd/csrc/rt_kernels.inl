@@ -289,104 +289,148 @@ DEVI void cswap(float &ka, int &ra, float &kb, int &rb) {
   const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
   ka = k0; kb = k1; ra = r0; rb = r1;
 }
-// entry / exit / verdict of the four child boxes of one record.
-//   MODE 0  first pass of the exact-quotient path; returns true if a verdict is in doubt
-//   MODE 1  correctly rounded quotients by Markstein's corrections (mdiv)
-//   MODE 2  plain divisions and the reference's six comparisons (zero / denormal direction
-//           components, out-of-range scenes)
-// The verdict `entry > exit` needs the correctly rounded quotients only when the two are within
-// rounding of each other.  First pass: q~ = RN(a * RN(1/d)), which is within 3.1 * 2^-24 |q~| of the
-// correctly rounded q = RN(a/d) (two roundings against one; no under/overflow on this path:
-// |d| in [2^-40, 2^40], a = 0 or in [2^-59, 2^60]); max and min keep that bound
-// (|entry - entry~| <= eps |entry~|, likewise exit; eps = 2^-22).  A slab's entry never exceeds its
-// OWN exit on this path (box min <= max, rounding is monotone) -- and for a flat box, an
-// axis-aligned triangle's, the two are one number in both arithmetics, so exit~ - entry~ = 0 exactly
-// whenever a ray hits it: that difference cannot be the yardstick.  The verdict is "every entry <=
-// every exit of ANOTHER axis", i.e. the smallest cross-axis gap
-//   g = min_j (exit_j - max_{i != j} entry_i) >= 0,
-// and with D = 2 eps (|entry~| + |exit~|):   g~ > D => hit,   g~ < -D => miss   (if the order of some
-// cross pair flipped under the roundings although |g~| > D, its two members would lie between
-// exit~ and entry~ and their error would be below D).  Only what is in doubt -- a ray grazing a box
-// edge to 7 digits -- is redone with the exact quotients: 6 multiplications and 8 more operations
-// per box instead of 30 fused ones, same verdicts bit for bit.  Pruning and ordering work on
-// entry~/exit~ (they have a 2^-12 margin).
-template <bool LDS, int MODE>
-DEVI bool wide_boxes(const RenderParams &P, const float4 *sc, int cur, V3 o, V3 d, const RayDiv &rd, const RaySign &sg,
-                     float &e0, float &e1, float &e2, float &e3, float &x0, float &x1, float &x2, float &x3, bool &h0,
-                     bool &h1, bool &h2, bool &h3) {
+// ---- conservative box tests for the inner levels, exact verdicts where they matter ------------
+// The reference tests a primitive iff hitsBox accepts the box of every BVH node from the root down
+// to the primitive's leaf (RayTracer.hs:404-412).  On the exact-quotient path a box's verdict
+// implies its ancestors' (a parent's planes are the min / max of its children's and every rounding
+// is monotone: parent entry <= child entry, parent exit >= child exit on each axis), so the
+// primitives the reference tests are exactly those whose LEAF box it accepts.  The pruned traversal
+// therefore only needs the exact verdict of a leaf box, and only when it matters: when a primitive
+// of that leaf has become the ray's hit (leaf_box_clear below; once per traversal).  Every
+// box test on the way down may err on the side of "hit": it costs 6 fused multiply-adds per box
+// against a per-ray reciprocal, no divisions and no corrections.
+//
+// Per ray: r~ = v_rcp_f32(d) (1 ulp), or~ = RN(o * r~).  Slab distance t~ = RN(c * r~ - or~) against
+// the reference's t = RN(RN(c - o) / d):  |t~ - t| <= 5.2 u |t~| + 1.02 u |or~|  (u = 2^-24: the
+// reciprocal 2 u, the product rounding inside or~, the final rounding, and t's own two roundings;
+// the cancellation c * r~ - or~ is exact inside the FMA).  With E~ = max of the three entries and
+// X~ = min of the three exits:  reference accepts (E <= X)  =>  E~ - X~ <= 5.2 u (|E~| + |X~|) +
+// 2.04 u max |or~|  <  thr := 2^-21 (|E~| + |X~|) + 2^-22 max |or~|.  A box is skipped only when
+// E~ - X~ > thr; range pruning uses E~ - thr and X~ + thr.  No overflow or NaN on this path:
+// |d| in [2^-40, 2^40], |o| and box coordinates <= 2^59 (other rays and scenes take the
+// plain-division path below, which is exact at every node).
+struct RayBox {
+  float rx, ry, rz;  // ~ 1 / d
+  float ox, oy, oz;  // RN(o * r~)
+  float b0;          // 2^-22 max |or~|
+  bool ok;           // the conservative path is valid for this ray
+};
+DEVI RayBox make_raybox(const RenderParams &P, V3 o, V3 d) {
+  RayBox b;
+  b.rx = __builtin_amdgcn_rcpf(d.x);
+  b.ry = __builtin_amdgcn_rcpf(d.y);
+  b.rz = __builtin_amdgcn_rcpf(d.z);
+#ifdef RT_BOX_SUBMUL
+  b.ox = b.oy = b.oz = b.b0 = 0.0f;
+#else
+  b.ox = o.x * b.rx;
+  b.oy = o.y * b.ry;
+  b.oz = o.z * b.rz;
+  b.b0 = 2.384185791015625e-07f * fmaxf(fmaxf(fabsf(b.ox), fabsf(b.oy)), fabsf(b.oz));
+#endif
+  constexpr float DLO = 9.094947017729282e-13f /*2^-40*/, DHI = 1099511627776.0f /*2^40*/,
+                  OHI = 5.764607523034235e17f /*2^59*/;
+  // (every comparison is false for a NaN)
+  b.ok = P.boxes_safe && fabsf(d.x) >= DLO && fabsf(d.y) >= DLO && fabsf(d.z) >= DLO && fabsf(d.x) <= DHI &&
+         fabsf(d.y) <= DHI && fabsf(d.z) <= DHI && fabsf(o.x) <= OHI && fabsf(o.y) <= OHI && fabsf(o.z) <= OHI;
+  return b;
+}
+
+// Leaf boxes (exact verdicts): two float4 per primitive record, the box of the record's LEAF:
+// (xmin, xmax, ymin, ymax) (zmin, zmax, -, -)
+template <bool LDS>
+DEVI const float4 *leafbox_rec(const RenderParams &P, const float4 *sc, int prim) {
+  return LDS ? sc + (P.lds_leafbox_base + prim * 2) : P.leafbox + (size_t)prim * 2;
+}
+// Does the reference's hitsBox (BoundingVolumeHierarchy.hs:191-204) CERTAINLY accept the box of the
+// leaf that holds record `prim`?  (Rays on the conservative path: rb.ok.)  Quotients by the ray's
+// 1-ulp reciprocal: q~ = RN(a * r~) is within 4.1 u |q~| of the correctly rounded RN(a / d).  The
+// verdict "every slab entry <= every exit of ANOTHER axis" is the sign of the smallest cross-axis
+// gap g = min_j (exit_j - max_{i != j} entry_i), and with D = 2^-20 (|E~| + |X~|) (eps = 2^-21 >=
+// 4.1 u each): g~ > D => the reference accepts (had the order of a cross pair flipped under the
+// roundings although |g~| > D, its two members would lie between X~ and E~ and their error would
+// be below D).  A slab's entry never exceeds its OWN exit here (box min <= max, monotone rounding),
+// and for a flat box -- an axis-aligned triangle's -- the two are one number, so the own-axis gap
+// is no yardstick.  Anything else (a ray grazing a box edge to 7 digits, a miss, a NaN) is not
+// decided here: the caller walks the tree again on the plain-division path, which is the
+// reference's own arithmetic at every node.
+template <bool LDS>
+DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o, V3 d, const RayBox &rb) {
+  const float4 *bp = leafbox_rec<LDS>(P, sc, prim);
+  const float4 b0 = bp[0], b1 = bp[1];
+  const float l = b0.x, r = b0.y, bo = b0.z, t = b0.w, n = b1.x, f = b1.y;
+  const float tx0 = ((d.x >= 0 ? l : r) - o.x) * rb.rx, tx1 = ((d.x >= 0 ? r : l) - o.x) * rb.rx;
+  const float ty0 = ((d.y >= 0 ? bo : t) - o.y) * rb.ry, ty1 = ((d.y >= 0 ? t : bo) - o.y) * rb.ry;
+  const float tz0 = ((d.z >= 0 ? n : f) - o.z) * rb.rz, tz1 = ((d.z >= 0 ? f : n) - o.z) * rb.rz;
+  const float mx = fmaxf(ty0, tz0), my = fmaxf(tx0, tz0), mz = fmaxf(tx0, ty0);
+  const float E = fmaxf(tx0, mx), X = fminf(fminf(tx1, ty1), tz1);
+  const float g = fminf(fminf(tx1 - mx, ty1 - my), tz1 - mz);
+  return g > 9.5367431640625e-07f * (fabsf(E) + fabsf(X));
+}
+
+// Four box tests from one wide record, range pruning, then the children that remain go on the
+// stack farthest first and the nearest becomes current (or pop, or stop).  The stack writes are
+// unconditional -- a slot above the top is scratch -- so the step has no divergent pushes.
+// all_ok: every lane of the wave is on the conservative path (RayBox::ok); otherwise the whole
+// wave takes plain divisions and the reference's comparisons (exact at every node).
+// A slot without a child holds an inverted box (min = 2^58, max = -2^58): E~ - X~ >= 2^59 |r~|,
+// far beyond thr, so it is never entered on the conservative path.
+template <bool COUNT, bool LDS>
+DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
+                    const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
   const float4 *np = wnode_rec<LDS>(P, sc, cur);
-  if (MODE == 2) {
+  const float4 rf = np[6];
+  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+  if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+  // range pruning as in node_step
+  const float lim = prune_limit(best_t);
+  float e0, e1, e2, e3;
+  bool h0, h1, h2, h3;
+  if (all_ok) {
+    const float4 nx = np[sg.x], fx = np[sg.x ^ 1], ny = np[2 + sg.y], fy = np[2 + (sg.y ^ 1)], nz = np[4 + sg.z],
+                 fz = np[4 + (sg.z ^ 1)];
+#ifdef RT_BOX_SUBMUL
+#define RT_SLABS(C_)                                                                                \
+    const float tx0 = (nx.C_ - o.x) * rb.rx, tx1 = (fx.C_ - o.x) * rb.rx;                           \
+    const float ty0 = (ny.C_ - o.y) * rb.ry, ty1 = (fy.C_ - o.y) * rb.ry;                           \
+    const float tz0 = (nz.C_ - o.z) * rb.rz, tz1 = (fz.C_ - o.z) * rb.rz;
+#else
+#define RT_SLABS(C_)                                                                                                \
+    const float tx0 = __builtin_fmaf(nx.C_, rb.rx, -rb.ox), tx1 = __builtin_fmaf(fx.C_, rb.rx, -rb.ox);             \
+    const float ty0 = __builtin_fmaf(ny.C_, rb.ry, -rb.oy), ty1 = __builtin_fmaf(fy.C_, rb.ry, -rb.oy);             \
+    const float tz0 = __builtin_fmaf(nz.C_, rb.rz, -rb.oz), tz1 = __builtin_fmaf(fz.C_, rb.rz, -rb.oz);
+#endif
+#define RT_WIDE_CHILD(C_, E_, H_)                                                                                   \
+  {                                                                                                                 \
+    RT_SLABS(C_)                                                                                                    \
+    E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                               \
+    const float X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
+    const float thr = __builtin_fmaf(fabsf(E_) + fabsf(X_), 4.76837158203125e-07f, rb.b0);                          \
+    H_ = (E_ - X_ <= thr) && !(E_ - thr > lim || X_ + thr < BEHIND);                                                \
+  }
+    RT_WIDE_CHILD(x, e0, h0)
+    RT_WIDE_CHILD(y, e1, h1)
+    RT_WIDE_CHILD(z, e2, h2)
+    RT_WIDE_CHILD(w, e3, h3)
+#undef RT_WIDE_CHILD
+#undef RT_SLABS
+  } else {
+    // plain divisions (a zero / denormal / huge direction component, out-of-range origin or scene);
+    // a NaN entry or exit is ignored by max / min and never prunes
     const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5];
+    RayDiv rd;
+    rd.rx = rd.ry = rd.rz = 1.0f;
+    rd.safe = false;
+    float x0, x1, x2, x3;
     h0 = hits_box<false>(o, d, rd, a0.x, a1.x, a2.x, a3.x, a4.x, a5.x, e0, x0);
     h1 = hits_box<false>(o, d, rd, a0.y, a1.y, a2.y, a3.y, a4.y, a5.y, e1, x1);
     h2 = hits_box<false>(o, d, rd, a0.z, a1.z, a2.z, a3.z, a4.z, a5.z, e2, x2);
     h3 = hits_box<false>(o, d, rd, a0.w, a1.w, a2.w, a3.w, a4.w, a5.w, e3, x3);
-    return false;
+    h0 = h0 && r0 != REF_NONE && !(e0 > lim || x0 < BEHIND);
+    h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < BEHIND);
+    h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
+    h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
   }
-  const float4 nx = np[sg.x], fx = np[sg.x ^ 1], ny = np[2 + sg.y], fy = np[2 + (sg.y ^ 1)], nz = np[4 + sg.z],
-               fz = np[4 + (sg.z ^ 1)];
-  constexpr float BAND = 4.76837158203125e-07f;  // 2 eps = 2^-21
-  bool doubt = false;
-#define RT_WIDE_CHILD(C_, E_, X_, H_)                                                                     \
-  {                                                                                                       \
-    if (MODE == 1) {                                                                                      \
-      const float tx0 = mdiv(nx.C_ - o.x, d.x, rd.rx), tx1 = mdiv(fx.C_ - o.x, d.x, rd.rx);               \
-      const float ty0 = mdiv(ny.C_ - o.y, d.y, rd.ry), ty1 = mdiv(fy.C_ - o.y, d.y, rd.ry);               \
-      const float tz0 = mdiv(nz.C_ - o.z, d.z, rd.rz), tz1 = mdiv(fz.C_ - o.z, d.z, rd.rz);               \
-      E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                   \
-      X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
-      H_ = !(E_ > X_);                                                                                    \
-    } else {                                                                                              \
-      const float tx0 = (nx.C_ - o.x) * rd.rx, tx1 = (fx.C_ - o.x) * rd.rx;                               \
-      const float ty0 = (ny.C_ - o.y) * rd.ry, ty1 = (fy.C_ - o.y) * rd.ry;                               \
-      const float tz0 = (nz.C_ - o.z) * rd.rz, tz1 = (fz.C_ - o.z) * rd.rz;                               \
-      const float mx = fmaxf(ty0, tz0), my = fmaxf(tx0, tz0), mz = fmaxf(tx0, ty0);                       \
-      E_ = fmaxf(tx0, mx);                                                                                \
-      X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
-      const float g = fminf(fminf(tx1 - mx, ty1 - my), tz1 - mz);                                         \
-      H_ = g >= 0;                                                                                        \
-      doubt |= fabsf(g) <= BAND * (fabsf(E_) + fabsf(X_));                                                \
-    }                                                                                                     \
-  }
-  RT_WIDE_CHILD(x, e0, x0, h0)
-  RT_WIDE_CHILD(y, e1, x1, h1)
-  RT_WIDE_CHILD(z, e2, x2, h2)
-  RT_WIDE_CHILD(w, e3, x3, h3)
-#undef RT_WIDE_CHILD
-  return doubt;
-}
-
-// Four hitsBox tests from one record, range pruning, then the children that remain go on the
-// stack farthest first and the nearest becomes current (or pop, or stop).  The stack writes are
-// unconditional -- a slot above the top is scratch -- so the step has no divergent pushes.
-template <bool COUNT, bool LDS>
-DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
-                    const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
-  float e0, e1, e2, e3, x0, x1, x2, x3;
-  bool h0, h1, h2, h3;
-  if (all_safe) {
-#ifdef RT_FAST_MATH
-    wide_boxes<LDS, 0>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
-#else
-    if (wide_boxes<LDS, 0>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3)) {
-      // (rare; the record is read again rather than kept in registers across the branch)
-      asm volatile("" ::: "memory");
-      wide_boxes<LDS, 1>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
-    }
-#endif
-  } else {
-    wide_boxes<LDS, 2>(P, sc, cur, o, d, rd, sg, e0, e1, e2, e3, x0, x1, x2, x3, h0, h1, h2, h3);
-  }
-  const float4 rf = wnode_rec<LDS>(P, sc, cur)[6];
-  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
-  if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
-  // range pruning as in node_step (a NaN entry/exit -- plain-division path only -- is ignored by
-  // max/min and never prunes)
-  const float lim = prune_limit(best_t);
-  h0 = h0 && r0 != REF_NONE && !(e0 > lim || x0 < BEHIND);
-  h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < BEHIND);
-  h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
-  h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
   const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
   // sort by entry distance, misses last (5 compare-exchanges)
   // (a hit's key is capped below a miss's +inf -- also a NaN or +inf entry, which fminf turns into
@@ -417,13 +461,16 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
 }
 
 // One leaf: records first .. first+count-1 (reversed list order), then pop or stop.
-template <bool ANY, bool COUNT, bool LDS>
-DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, float tlimit,
-                    float &best_t, int &best_p, int &cur, int &sp, Counters &cn) {
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
+DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
+                    bool verify_now, bool &redo, float tlimit, float &best_t, int &best_p, int &cur, int &sp,
+                    Counters &cn) {
   int first = -1 - cur;
   const float4 *pp = prim_rec<LDS>(P, sc, first);
   int count = __float_as_int(pp[3].w);
-  bool done = false;
+  // the leaf's candidate: what the ray's hit would become if the reference visits this leaf
+  float lt = best_t;
+  int lp = best_p;
   for (int k = 0; k < count; ++k) {
     const float4 *q = pp + (size_t)k * (LDS ? LDS_REC_F4 : PRIM_F4);
     float4 q0 = q[0], q1 = q[1], q3 = q[3];
@@ -437,21 +484,26 @@ DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
       ok = hit_sphere(o, d, q0, q1.x, t);
       if (COUNT) cn.sph += 1;
     }
-    if (ok) {
-      if (ANY) {
-        if (t < tlimit) {
-          best_t = t;
-          best_p = first + k;
-          done = true;
-          break;
-        }
-      } else if (t < best_t || (t == best_t && first + k > best_p)) {
-        best_t = t;
-        best_p = first + k;
-      }
+    if (ok && (ANY ? (t < tlimit) : (t < lt || (t == lt && first + k > lp)))) {
+      lt = t;
+      lp = first + k;
+      if (ANY) break;
     }
   }
-  if (done) {
+  bool got = lp != best_p;
+  // PRUNE: only now does it matter whether the reference visits this leaf at all.  The closest-hit
+  // and single-light shadow traversals put the question off to their end (traverse); the
+  // shadow-ray pool asks here, and a ray without a clear answer starts again on the exact path.
+  redo = false;
+  if (PRUNE && verify_now && got && !leaf_box_clear<LDS>(P, sc, lp, o, d, rb)) {
+    got = false;
+    redo = true;
+  }
+  if (got) {
+    best_t = lt;
+    best_p = lp;
+  }
+  if (ANY && got) {
     cur = STOP;
   } else if (sp > 0) {
     --sp;
@@ -464,9 +516,27 @@ DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
 // One inner-node step of either tree: the pruned traversal walks the wide records.
 template <bool PRUNE, bool COUNT, bool LDS>
 DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
-                     const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
-  if (PRUNE) wide_step<COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
+                     const RayBox &rb, const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
+  if (PRUNE) wide_step<COUNT, LDS>(P, sc, stack, lane, o, d, rb, sg, all_safe, best_t, cur, sp, cn);
   else node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
+}
+
+// Per-ray constants of the box tests: the exact reciprocals of the reference-visit mode, or the
+// conservative test's (pruned mode); `safe` = this ray may take the mode's fast path.
+template <bool PRUNE>
+DEVI void ray_setup(const RenderParams &P, V3 o, V3 d, RayDiv &rd, RayBox &rb, bool &safe) {
+  rd.rx = rd.ry = rd.rz = 1.0f;
+  rd.safe = true;
+  rb.rx = rb.ry = rb.rz = 1.0f;
+  rb.ox = rb.oy = rb.oz = rb.b0 = 0.0f;
+  rb.ok = true;
+  if (PRUNE) {
+    rb = make_raybox(P, o, d);
+    safe = rb.ok;
+  } else {
+    rd = make_raydiv(P, o, d);
+    safe = rd.safe;
+  }
 }
 
 template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
@@ -476,41 +546,65 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   best_p = -1;
   int sp = 0;
   int cur = (active && P.has_root) ? 0 : STOP;
-  const RayDiv rd = make_raydiv(P, o, d);
+  RayDiv rd;
+  RayBox rb;
+  bool safe;
+  ray_setup<PRUNE>(P, o, d, rd, rb, safe);
   const RaySign sg = make_sign(d);
   // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
   // denormal direction component, or an out-of-range scene)
-  const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
-  // "while-while" form: all lanes first descend until each stands on a leaf (or is done),
-  // then the leaves are processed together -- node code and primitive code are not
-  // interleaved per iteration, which keeps more lanes busy in both.
-  if (!LDS) {
-    // scenes too big for LDS (deep trees, divergent rays): each iteration runs whichever of the
-    // two bodies more lanes are waiting for, instead of descending until every lane stands on
-    // a leaf (mesh workload 6 % faster single-frame; the small LDS scenes are faster while-while)
-    for (;;) {
-      const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
-      if ((at_node | at_leaf) == 0) break;
-      if (at_node >= at_leaf) {
-        if (cur >= 0) {
-          DIV_COUNT(cn, ANY ? 2 : 0);
-          inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
+  bool all_safe = __ballot(cur != STOP && !safe) == 0ull;
+  // Pruned mode: whether the reference accepts the winning primitive's leaf box is asked once, when
+  // the traversal is over (leaf_box_clear: ~30 instructions per traversal).  A lane without a clear
+  // "yes" -- about one ray in a million grazes a box edge that closely -- walks the tree again on
+  // the plain-division path, where every box test is the reference's own.
+  bool redo_unused;
+  for (;;) {
+    if (!LDS) {
+      // scenes too big for LDS (deep trees, divergent rays): each iteration runs whichever of the
+      // two bodies more lanes are waiting for, instead of descending until every lane stands on
+      // a leaf (mesh workload 6 % faster single-frame; the small LDS scenes are faster while-while)
+      for (;;) {
+        const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
+        if ((at_node | at_leaf) == 0) break;
+        if (at_node >= at_leaf) {
+          if (cur >= 0) {
+            DIV_COUNT(cn, ANY ? 2 : 0);
+            inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
+          }
+        } else if (cur < 0 && cur != STOP) {
+          DIV_COUNT(cn, ANY ? 3 : 1);
+          leaf_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, cn);
         }
-      } else if (cur < 0 && cur != STOP) {
-        DIV_COUNT(cn, ANY ? 3 : 1);
-        leaf_step<ANY, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, best_t, best_p, cur, sp, cn);
+      }
+    } else {
+      // "while-while" form: all lanes first descend until each stands on a leaf (or is done),
+      // then the leaves are processed together -- node code and primitive code are not
+      // interleaved per iteration, which keeps more lanes busy in both.
+      while (cur != STOP) {
+        while (cur >= 0) {
+          DIV_COUNT(cn, ANY ? 2 : 0);
+          inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
+        }
+        if (cur != STOP) {
+          DIV_COUNT(cn, ANY ? 3 : 1);
+          leaf_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, cn);
+        }
       }
     }
-    return;
-  }
-  while (cur != STOP) {
-    while (cur >= 0) {
-      DIV_COUNT(cn, ANY ? 2 : 0);
-      inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, best_t, cur, sp, cn);
-    }
-    if (cur != STOP) {
-      DIV_COUNT(cn, ANY ? 3 : 1);
-      leaf_step<ANY, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, best_t, best_p, cur, sp, cn);
+    // (waves on the plain-division path have tested every box exactly on the way down)
+    if (!PRUNE || !all_safe) break;
+#ifdef RT_NO_VERIFY
+    break;
+#endif
+    const bool bad = best_p >= 0 && !leaf_box_clear<LDS>(P, sc, best_p, o, d, rb);
+    if (__ballot(bad) == 0ull) break;
+    all_safe = false;
+    if (bad) {
+      best_t = ANY ? tlimit : INFINITY;
+      best_p = -1;
+      sp = 0;
+      cur = 0;
     }
   }
 }
@@ -590,8 +684,9 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
   float tlimit = 0.0f;
   RayDiv rd;
-  rd.rx = rd.ry = rd.rz = 1.0f;
-  rd.safe = true;
+  RayBox rb;
+  bool safe;
+  ray_setup<PRUNE>(P, mk(0, 0, 0), mk(1, 1, 1), rd, rb, safe);
   RaySign sg = make_sign(d);
   for (;;) {
     const unsigned long long idle = __ballot(cur == STOP);
@@ -618,7 +713,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
                __uint_as_float(pts[2 * 64 + owner]));
         light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
                   tlimit);
-        rd = make_raydiv(P, o, d);
+        ray_setup<PRUNE>(P, o, d, rd, rb, safe);
         sg = make_sign(d);
         sp = 0;
         cur = 0;
@@ -627,18 +722,24 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
     }
     const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
     if ((at_node | at_leaf) == 0) break;
-    const bool all_safe = __ballot(cur != STOP && !rd.safe) == 0ull;
+    const bool all_safe = __ballot(cur != STOP && !safe) == 0ull;
     if (at_node >= at_leaf) {
       if (cur >= 0) {
         DIV_COUNT(cn, 2);
-        inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, sg, all_safe, tlimit, cur, sp, cn);
+        inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, tlimit, cur, sp, cn);
       }
     } else if (cur < 0 && cur != STOP) {
       DIV_COUNT(cn, 3);
       float bt = tlimit;
       int bp = -1;
-      leaf_step<true, COUNT, LDS>(P, sc, stack, lane, o, d, tlimit, bt, bp, cur, sp, cn);
+      bool redo;
+      leaf_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, all_safe, redo, tlimit, bt, bp, cur, sp, cn);
       if (bp >= 0) atomicOr(&occl[owner], 1u << bit);
+      if (redo) {  // no clear verdict for the occluder's leaf box: this ray again, on the exact path
+        safe = false;
+        sp = 0;
+        cur = 0;
+      }
     }
   }
   __threadfence_block();
@@ -849,7 +950,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
-  const int rec_words = LDS ? (P.lds_prim_base + P.n_prim_recs * LDS_REC_F4) * 4 : 0;
+  const int rec_words = LDS ? P.lds_rec_f4 * 4 : 0;  // wide or binary records, primitive records, leaf boxes
   const int mat_words = LDS ? ((P.n_materials * 12 + 3) & ~3) : 0;
   const int scene_words = rec_words + mat_words;
   const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
@@ -872,6 +973,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       const int rec = i >> 2, part = i & 3;
       dst[P.lds_prim_base + rec * LDS_REC_F4 + part] = P.prims[(size_t)rec * PRIM_F4 + part];
     }
+    if (PRUNE)
+      for (int i = threadIdx.x; i < P.n_prim_recs * 2; i += 64 * WPB) dst[P.lds_leafbox_base + i] = P.leafbox[i];
     for (int i = threadIdx.x; i < P.n_materials * 12; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
     __syncthreads();
   }
