@@ -29,6 +29,8 @@ struct rt_ctx {
 
   // scene
   float4 *d_nodes = nullptr, *d_prims = nullptr, *d_wnodes = nullptr, *d_leafbox = nullptr;
+  float *d_materials12 = nullptr;  // rt_material as uploaded; d_materials holds the MAT_F-float device records
+  size_t cap_materials12 = 0;
   float *d_materials = nullptr, *d_lights = nullptr;
   size_t cap_nodes = 0, cap_prims = 0, cap_wnodes = 0, cap_leafbox = 0, cap_materials = 0, cap_lights = 0, cap_f6 = 0;  // bytes allocated
   void *h_stage = nullptr;  // pinned staging buffer of the uploads
@@ -671,6 +673,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     p.v[i] = cam.v[i];
     p.w[i] = cam.w[i];
     p.ambient[i] = cam.ambient[i];
+    p.w_dir[i] = (-cam.view_d) * cam.w[i];  // multiply ww (-vDt) (RayTracer.hs:197-199): f * a.x
   }
   p.tile_w = c->tiling.tile_w;
   p.tile_h = c->tiling.tile_h;
@@ -724,7 +727,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.lds_leafbox_base = p.lds_prim_base + c->n_prim_recs * LDS_REC_F4;
   p.lds_rec_f4 = p.lds_leafbox_base + (prune ? c->n_prim_recs * 2 : 0);  // leaf boxes: pruned traversal only
   p.leafbox = c->d_leafbox;
-  cfg.lds_scene_bytes = (size_t)p.lds_rec_f4 * 16 + (size_t)((c->n_materials * 12 + 3) & ~3) * 4;
+  cfg.lds_scene_bytes = (size_t)p.lds_rec_f4 * 16 + (size_t)c->n_materials * MAT_F * 4;
   cfg.lds_scene = c->lds_scene_mode != 0 && !cfg.count && cfg.lds_bytes + cfg.lds_scene_bytes <= 40 * 1024;
   int wpb = WAVES_PER_BLOCK;
   if (!cfg.lds_scene && c->lds_scene_mode != 0 && !cfg.count && cfg.prune &&
@@ -892,7 +895,7 @@ void rt_shutdown(rt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_leafbox, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
+  void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_leafbox, c->d_materials12, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
                   c->d_spheres, c->d_triangles, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
@@ -982,9 +985,13 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   if (std::getenv("RT_DEBUG_UPLOAD"))
     std::fprintf(stderr, "[rt_upload_scene] binary records %zu (depth %d), wide records %d, wide stack need %d (cap %d), primitives %zu\n",
                  rp.nodes.size() / 16, rp.max_depth, c->n_wnode_recs, wb.max_stack, wb.cap, rp.prims.size() / 16);
-  up.add(&c->d_materials, &c->cap_materials, sc->materials, (size_t)sc->n_materials * sizeof(rt_material));
+  up.add(&c->d_materials12, &c->cap_materials12, sc->materials, (size_t)sc->n_materials * sizeof(rt_material));
+  up.add(&c->d_materials, &c->cap_materials, nullptr, (size_t)std::max(1, sc->n_materials) * MAT_F * sizeof(float));
   up.add(&c->d_lights, &c->cap_lights, sc->lights, (size_t)sc->n_lights * sizeof(rt_light));
   if ((rc = up.run(c))) return rc;
+  (void)hipGetLastError();
+  launch_material_prep(c->d_materials12, c->d_materials, sc->n_materials, c->stream);
+  HIP_TRY(c, hipGetLastError());
   c->n_lights = sc->n_lights;
   c->n_materials = sc->n_materials;
   c->n_node_recs = (int)(rp.nodes.size() / 16);

@@ -50,6 +50,16 @@ constexpr int WNODE_F4 = 8;
 constexpr int LDS_WNODE_F4 = 9;  // LDS stride of a wide record: 36 dwords, walks all sixteen 4-bank groups
 constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)
 
+// Material record on the device, MAT_F floats: [0..11] rt_material (diffuse rgb, specular rgb, phong,
+// reflectivity, refractive index nt, attenuation rgb), then what getIndirectColor / refract
+// (RayTracer.hs:109-179) compute from the material alone, formed ONCE per scene by
+// material_prep_kernel with the very operations the reference performs per hit:
+//   [12] 1 / phong                      (:113, the glossy jitter's a)
+//   [13] (nt-1)*(nt-1) / ((nt+1)*(nt+1))  (:145, Schlick's r_0)
+//   [14] 1 / nt                         (:138 the index handed to refract on leaving; :166 n / nt, n = 1, on entering)
+//   [15] 1 / (1 / nt)                   (:166 n / nt on leaving)
+//   [16..18] exp(-attenuation)          (:139-141, k on leaving)      [19] unused
+constexpr int MAT_F = 20;
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
 constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
 constexpr int POINT_WORDS = 8 * 64;  // LDS per wave (multi-light builds): x, y, z, s0, s1, occlusion mask of the step's points, hand-out table, per-light masks
@@ -60,7 +70,7 @@ constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~
 struct RenderParams {
   const float4 *nodes;
   const float4 *prims;
-  const float *materials;  // 12 floats each, rt_material order
+  const float *materials;  // MAT_F floats each: rt_material's 12, then the per-material constants of getIndirectColor (below)
   const float *lights;     // 12 floats each, rt_light order
   const float *f6;         // [n_grids][spp][6]
   int n_lights, n_grids, spp, has_root;
@@ -69,6 +79,7 @@ struct RenderParams {
   float view_w, view_h, view_d, lens;
   float eye[3], u[3], v[3], w[3], ambient[3];
   float half_view_w, half_view_h, half_lens;  // view_w / 2, view_h / 2, lens / 2 (IEEE, host)
+  float w_dir[3];                             // (-view_d) * w, the camera's w term of getRay (host, same products)
   // tiling / partition
   int tile_w, tile_h, tiles_x, tile_samples;
   int rank, nranks, n_local_tiles, compact;
@@ -119,6 +130,7 @@ struct LaunchCfg {
 // one per arithmetic mode (separate translation units, different -ffp-contract)
 void launch_render_strict(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
 void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s);
+void launch_material_prep(const float *materials12, float *materials_dev, int n, hipStream_t s);  // strict arithmetic
 int occupancy_strict(const LaunchCfg &cfg);  // resident blocks per CU of the kernel cfg selects
 int occupancy_fma(const LaunchCfg &cfg);
 

@@ -766,19 +766,26 @@ DEVI void orthonormal(V3 w, V3 &u, V3 &v) {
 // getRay (RayTracer.hs:183-205)
 DEVI void get_ray(const RenderParams &P, float i, float j, float r1, float r2, V3 &base, V3 &dirn) {
   float lens = P.lens;
-  V3 eye = ld3(P.eye), u = ld3(P.u), v = ld3(P.v), ww = ld3(P.w);
-  float r1l = r1 * lens, r2l = r2 * lens, l2 = P.half_lens;  // lens / 2, divided on the host
-  V3 ru = subt(mk(u.x * r1l, u.y * r1l, u.z * r1l), mk(u.x * l2, u.y * l2, u.z * l2));
-  V3 rv = subt(mk(v.x * r2l, v.y * r2l, v.z * r2l), mk(v.x * l2, v.y * l2, v.z * l2));
-  base = add(eye, add(ru, rv));
-  float vWd = P.view_w, vHt = P.view_h, vDt = P.view_d;
+  V3 eye = ld3(P.eye), u = ld3(P.u), v = ld3(P.v);
+  if (lens == 0) {
+    // pinhole: ru = u * (r1 * 0) - u * (0 / 2) and rv likewise are +0 per component (x * 0 - x * 0
+    // for finite x; a negative r1 could make it -0, which eye + (ru + rv) absorbs the same way
+    // unless an eye coordinate is itself -0 -- a zero origin's sign reaches no quotient), so
+    // base = eye + 0: 3 additions for 24 operations
+    base = add(eye, mk(0.0f, 0.0f, 0.0f));
+  } else {
+    float r1l = r1 * lens, r2l = r2 * lens, l2 = P.half_lens;  // lens / 2, divided on the host
+    V3 ru = subt(mk(u.x * r1l, u.y * r1l, u.z * r1l), mk(u.x * l2, u.y * l2, u.z * l2));
+    V3 rv = subt(mk(v.x * r2l, v.y * r2l, v.z * r2l), mk(v.x * l2, v.y * l2, v.z * l2));
+    base = add(eye, add(ru, rv));
+  }
+  float vWd = P.view_w, vHt = P.view_h;
   float iWd = (float)P.W, iHt = (float)P.H;
   float u_world = i * vWd / iWd - P.half_view_w;  // vWd / 2.0 and vHt / 2.0: same IEEE quotients,
   float v_world = j * vHt / iHt - P.half_view_h;  // formed once on the host
-  float w_world = -vDt;
   V3 u_dir = multiply(u, u_world);
   V3 v_dir = multiply(v, v_world);
-  V3 w_dir = multiply(ww, w_world);
+  V3 w_dir = ld3(P.w_dir);  // multiply w (-vDt), formed once on the host (the same three products)
   V3 dir = add(w_dir, add(u_dir, v_dir));
   V3 fdir = subt(add(dir, eye), base);
   dirn = normalize(fdir);
@@ -800,6 +807,12 @@ constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 #ifdef RT_PROFILE_PHASES
 #define PH_DECL unsigned long long ph_start = __builtin_amdgcn_s_memtime(), ph_t = ph_start, ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0, ph_lanes = 0
 #define PH_MARK(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#elif defined(RT_ASM_MARKS)
+// (static instruction counts per phase: markers in the assembly listing, tools/phase_static.py)
+#define PH_DECL
+#define PH_STR2(x) #x
+#define PH_STR(x) PH_STR2(x)
+#define PH_MARK(i) asm volatile("; PHASE_MARK " #i " line " PH_STR(__LINE__))
 #else
 #define PH_DECL
 #define PH_MARK(i)
@@ -821,20 +834,27 @@ constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 // fmaxf/fminf would DROP a NaN operand and turn it into -2^12, cancelling a sibling's +2^12.  The
 // reference's pixel is NaN in that case and `truncate NaN` is garbage (Main.hs:131), so there is no
 // value to match; NaN pixels are excluded from parity and counted by the oracle.
-DEVI long long to_fixed(float c) {
+// The fixed-point number (long long)(c * 2^34) is formed as two 32-bit halves, hi * 2^24 + lo with
+// |hi| <= 2^22, |lo| < 2^24 and both of c's sign: x = c * 2^34 is exact (a power of two), h = trunc(x * 2^-24) and the
+// remainder x - h * 2^24 are exact floats, and truncating the remainder truncates x.  Up to 64 such
+// pairs are summed half by half in 32-bit registers (|sums| < 2^30) -- one DPP add per value and
+// scan stage instead of two moves and a 64-bit add -- and joined where a sum leaves the wave.
+DEVI void to_fixed2(float c, int &hi, int &lo) {
   c = (c != c) ? 4096.0f : fminf(fmaxf(c, -4096.0f), 4096.0f);
-  return (long long)(c * 17179869184.0f);  // 2^34
+  const float x = c * 17179869184.0f;                              // 2^34
+  const float h = __builtin_truncf(x * 5.9604644775390625e-08f);   // 2^-24
+  const float l = __builtin_fmaf(-h, 16777216.0f, x);
+  hi = (int)h;
+  lo = (int)l;
 }
+DEVI long long join_fixed(int hi, int lo) { return (long long)hi * 16777216ll + (long long)lo; }
 
-// Data-parallel-primitive move of a 64-bit value: lane i receives the value of the lane that
-// `CTRL` names (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143), 0 when that
-// lane does not exist or the lane's row is not in ROW_MASK.  All 64 lanes must be active.
+// Data-parallel-primitive add: lane i adds the value of the lane that `CTRL` names (row_shr:n =
+// 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143), 0 when that lane does not exist or the
+// lane's row is not in ROW_MASK.  All 64 lanes must be active.
 template <int CTRL, int ROW_MASK = 0xF>
-DEVI long long dpp_mov64(long long v) {
-  int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
-  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+DEVI int dpp_get(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
 
 // Packet fetch.  PACKET_SHARDS ticket counters (one 128-B line each); ticket i of shard
@@ -951,7 +971,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
   const int rec_words = LDS ? P.lds_rec_f4 * 4 : 0;  // wide or binary records, primitive records, leaf boxes
-  const int mat_words = LDS ? ((P.n_materials * 12 + 3) & ~3) : 0;
+  const int mat_words = LDS ? P.n_materials * MAT_F : 0;
   const int scene_words = rec_words + mat_words;
   const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
   if (LDS) {
@@ -975,7 +995,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     }
     if (PRUNE)
       for (int i = threadIdx.x; i < P.n_prim_recs * 2; i += 64 * WPB) dst[P.lds_leafbox_base + i] = P.leafbox[i];
-    for (int i = threadIdx.x; i < P.n_materials * 12; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
+    for (int i = threadIdx.x; i < P.n_materials * MAT_F; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
     __syncthreads();
   }
   unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
@@ -1035,7 +1055,9 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     unsigned pix;  // local pixel index: ltile * tile_px + (pixel in tile)
     int px = 0, py = 0, smp = 0;
     if (level == 1) {
-      const int packet_id = cur_packet >> 7, code = cur_packet & 127;
+      // (the order[] word is the same in every lane: saying so keeps the tile arithmetic scalar)
+      const int packet_word = wave_uniform(cur_packet);
+      const int packet_id = packet_word >> 7, code = packet_word & 127;
       const int ltile = (int)fdiv((unsigned)packet_id, P.fd_groups_per_tile), grp = packet_id - ltile * P.groups_per_tile;
       const int gtile = P.rank + ltile * P.nranks;
       const int tyi = (int)fdiv((unsigned)gtile, P.fd_tiles_x);
@@ -1149,7 +1171,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         n = divide(subt(pt, mk(q0.x, q0.y, q0.z)), q0.w);  // getNormal, sphere (:76)
       }
     }
-    const float *M = LDS ? ldsM + mat * 12 : P.materials + (size_t)mat * 12;
+    const float *M = LDS ? ldsM + mat * MAT_F : P.materials + (size_t)mat * MAT_F;
     const V3 v = mk(-d.x, -d.y, -d.z);  // :65
 
     // getDirectColor (:81-106).  The reference folds the light list from the right:
@@ -1240,8 +1262,12 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     {
       V3 c = cmul(W, clr);
       const bool contrib = (level == 1) ? active : hit;
-      long long cr = contrib ? to_fixed(c.x) : 0, cg = contrib ? to_fixed(c.y) : 0,
-                cb = contrib ? to_fixed(c.z) : 0;
+      int v[6] = {0, 0, 0, 0, 0, 0};  // (hi, lo) of red, green, blue
+      if (contrib) {
+        to_fixed2(c.x, v[0], v[1]);
+        to_fixed2(c.y, v[2], v[3]);
+        to_fixed2(c.z, v[4], v[5]);
+      }
       bool tail;
       if (level == 1 && (P.spp == 4 || P.spp == 16 || P.spp == 64)) {
         // primaries: a pixel's samples are spp consecutive lanes starting at a multiple of spp,
@@ -1249,23 +1275,30 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         // (out-of-row sources read 0) instead of LDS-routed shuffles
         const int in_run = lane & (P.spp - 1);
         tail = active && in_run == P.spp - 1;
-        { long long ur = dpp_mov64<0x111>(cr), ug = dpp_mov64<0x111>(cg), ub = dpp_mov64<0x111>(cb);
-          if (in_run >= 1) { cr += ur; cg += ug; cb += ub; } }
-        { long long ur = dpp_mov64<0x112>(cr), ug = dpp_mov64<0x112>(cg), ub = dpp_mov64<0x112>(cb);
-          if (in_run >= 2) { cr += ur; cg += ug; cb += ub; } }
-        if (P.spp >= 16) {
-          { long long ur = dpp_mov64<0x114>(cr), ug = dpp_mov64<0x114>(cg), ub = dpp_mov64<0x114>(cb);
-            cr += ur; cg += ug; cb += ub; }
-          { long long ur = dpp_mov64<0x118>(cr), ug = dpp_mov64<0x118>(cg), ub = dpp_mov64<0x118>(cb);
-            cr += ur; cg += ug; cb += ub; }
+        if (P.spp == 4) {
+          // runs of 4 inside a row: the shifted value must come from the lane's own run
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const int u = dpp_get<0x111>(v[k]); v[k] += in_run >= 1 ? u : 0; }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const int u = dpp_get<0x112>(v[k]); v[k] += in_run >= 2 ? u : 0; }
+        } else {
+          // a run is a whole row (or four): what a row shift brings in from outside the row is 0
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x111>(v[k]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x112>(v[k]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x114>(v[k]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x118>(v[k]);
         }
         if (P.spp == 64) {
           // lane 15 of each row holds the row's sum: rows 1, 3 add their predecessor's
           // (row_bcast:15), then rows 2, 3 add lane 31's (row_bcast:31); lane 63 = wave sum
-          { long long ur = dpp_mov64<0x142, 0xA>(cr), ug = dpp_mov64<0x142, 0xA>(cg), ub = dpp_mov64<0x142, 0xA>(cb);
-            cr += ur; cg += ug; cb += ub; }
-          { long long ur = dpp_mov64<0x143, 0xC>(cr), ug = dpp_mov64<0x143, 0xC>(cg), ub = dpp_mov64<0x143, 0xC>(cb);
-            cr += ur; cg += ug; cb += ub; }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x142, 0xA>(v[k]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] += dpp_get<0x143, 0xC>(v[k]);
         }
       } else {
         const unsigned key = contrib ? pix : (0xC0000000u | (unsigned)lane);  // unique when idle
@@ -1281,8 +1314,13 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
           const int start = 63 - __clzll(upto);  // first lane of this lane's run
 #pragma unroll
           for (int dlt = 1; dlt < scan_span; dlt <<= 1) {
-            long long ur = __shfl_up(cr, dlt), ug = __shfl_up(cg, dlt), ub = __shfl_up(cb, dlt);
-            if (lane - dlt >= start) { cr += ur; cg += ug; cb += ub; }
+            int u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = __shfl_up(v[k], dlt);
+            if (lane - dlt >= start) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) v[k] += u[k];
+            }
           }
         }
       }
@@ -1290,13 +1328,14 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       // return value (fire and forget; associative, so still order-independent and exact)
 #ifndef RT_DEBUG_NO_ACC
       if (tail) {
+        const long long cr = join_fixed(v[0], v[1]), cg = join_fixed(v[2], v[3]), cb = join_fixed(v[4], v[5]);
         unsigned long long *a = reinterpret_cast<unsigned long long *>(acc + (size_t)pix * 3);
         if (cr) __hip_atomic_fetch_add(a + 0, (unsigned long long)cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cg) __hip_atomic_fetch_add(a + 1, (unsigned long long)cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cb) __hip_atomic_fetch_add(a + 2, (unsigned long long)cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #else
-      if (tail && cr == 0x7fffffffffffffffll) acc[0] = cg + cb;
+      if (tail && v[0] == 0x7fffffff) acc[0] = v[1] + v[2];
 #endif
     }
 
@@ -1307,23 +1346,33 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       V3 refl_v = mk(0, 0, 1), tdir = mk(0, 0, 1), w_refl = mk(0, 0, 0), w_refr = mk(0, 0, 0);
       if (hit) {
         V3 spec = ld3(M + 3);
-        float phong = M[6], reflx = M[7], nt = M[8];
+        float reflx = M[7], nt = M[8];
         V3 f_refl = cscale(spec, reflx);
         e_refl = true;
         if (nt != 0) {
+          // Entering (dn < 0): refract dir n nt, k = 1, c = -dn.  Leaving: refract dir (-n) (1 / nt),
+          // k = exp(-attenuation), c = tdir . n (:134-143).  One body serves both: -n is exact, so
+          // dot dir (-n) = -dn and (-n) * (-dn) = n * dn bit for bit; what differs is the index, its
+          // reciprocal (material constants, MAT_F) and the side the normal is taken from.
+          const float dn = dot(d, n);
+          const bool entering = dn < 0;
+          const float ntv = entering ? nt : M[14];
+          const float n_over_nt = entering ? M[14] : M[15];
+          // refract (:162-170), n = 1
+          const float x = 1 - (1 - dn * dn) / ntv / ntv;
+          const bool has_t = !(x < 0);
           V3 k = mk(1, 1, 1);
-          float c;
-          bool has_t;
-          float dn = dot(d, n);
-          if (dn < 0) {
-            c = -dn;
-            has_t = refract(d, n, nt, tdir);
-          } else {
-            has_t = refract(d, multiply(n, -1), 1 / nt, tdir);
-            k = mk(expf(-M[9]), expf(-M[10]), expf(-M[11]));
+          float c = -dn;
+          if (has_t) {
+            const V3 y = multiply(subt(d, multiply(n, dn)), n_over_nt);
+            const float sx = entering ? sqrtf(x) : -sqrtf(x);   // (-n) * sqrt x = n * (-sqrt x)
+            tdir = normalize(subt(y, multiply(n, sx)));
+          }
+          if (!entering) {
+            k = mk(M[16], M[17], M[18]);
             c = has_t ? dot(tdir, n) : 0.0f;
           }
-          float r_0 = (nt - 1) * (nt - 1) / ((nt + 1) * (nt + 1));
+          const float r_0 = M[13];
           float om = 1 - c;
           float bigR = r_0 + (1 - r_0) * (om * om * om * om * om);
           if (has_t) {
@@ -1345,7 +1394,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
           V3 refl0 = reflect(d, n);
           V3 ou, ov;
           orthonormal(refl0, ou, ov);
-          float a = 1 / phong;
+          float a = M[12];  // 1 / phong
           float ju = -(a / 2) + s0 * a;
           float jv = -(a / 2) + s1 * a;
           refl_v = add(refl0, add(multiply(ou, ju), multiply(ov, jv)));
@@ -1476,7 +1525,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
     int cls = 0;
     if (inside && p >= 0) {
       int mat = __float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].y);
-      const float *M = P.materials + (size_t)mat * 12;
+      const float *M = P.materials + (size_t)mat * MAT_F;
       float refl = M[7];
       bool mirror = (M[3] * refl != 0) || (M[4] * refl != 0) || (M[5] * refl != 0);
       cls = (M[8] != 0) ? 3 : (mirror ? 2 : 1);
@@ -1575,6 +1624,26 @@ __global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
                             wcount[3][threadIdx.x]) * (threadIdx.x == 3 ? EXP : 1u);
     __syncthreads();
   }
+}
+
+// Per-material constants of getIndirectColor / refract (rt_device.h MAT_F), with the operations the
+// reference performs per hit (RayTracer.hs:113, 138-141, 145, 166); once per uploaded scene.
+__global__ void material_prep_kernel(const float *__restrict__ in12, float *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *m = in12 + (size_t)i * 12;
+  float *o = out + (size_t)i * MAT_F;
+  for (int k = 0; k < 12; ++k) o[k] = m[k];
+  const float phong = m[6], nt = m[8];
+  o[12] = 1 / phong;
+  o[13] = (nt - 1) * (nt - 1) / ((nt + 1) * (nt + 1));
+  const float inv_nt = 1 / nt;
+  o[14] = inv_nt;
+  o[15] = 1 / inv_nt;
+  o[16] = expf(-m[9]);
+  o[17] = expf(-m[10]);
+  o[18] = expf(-m[11]);
+  o[19] = 0.0f;
 }
 
 // avgColors (Surfaces.hs:15-18) per pixel: sum of the sample colours divided by the
