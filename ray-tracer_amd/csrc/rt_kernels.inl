@@ -375,7 +375,7 @@ DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o
 // wave takes plain divisions and the reference's comparisons (exact at every node).
 // A slot without a child holds an inverted box (min = 2^58, max = -2^58): E~ - X~ >= 2^59 |r~|,
 // far beyond thr, so it is never entered on the conservative path.
-template <bool COUNT, bool LDS>
+template <bool ANY, bool COUNT, bool LDS>
 DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
                     const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
   const float4 *np = wnode_rec<LDS>(P, sc, cur);
@@ -430,6 +430,27 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
     h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < BEHIND);
     h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
     h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
+  }
+  if (ANY) {
+    // "is anything in the way" does not care in which order the boxes are searched: the first
+    // child that passed becomes current, the others go on the stack as they come (no sort)
+    const bool p1 = h1 && h0, p2 = h2 && (h0 || h1), p3 = h3 && (h0 || h1 || h2);
+    unsigned *sl = stack + sp * 64 + lane;
+    sl[0] = (unsigned)r3;
+    sl += p3 ? 64 : 0;
+    sl[0] = (unsigned)r2;
+    sl += p2 ? 64 : 0;
+    sl[0] = (unsigned)r1;
+    sp += (int)p1 + (int)p2 + (int)p3;
+    if (h0 || h1 || h2 || h3) {
+      cur = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
+    } else if (sp > 0) {
+      --sp;
+      cur = (int)stack[sp * 64 + lane];
+    } else {
+      cur = STOP;
+    }
+    return;
   }
   const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
   // sort by entry distance, misses last (5 compare-exchanges)
@@ -514,10 +535,10 @@ DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
 }
 
 // One inner-node step of either tree: the pruned traversal walks the wide records.
-template <bool PRUNE, bool COUNT, bool LDS>
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
 DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
                      const RayBox &rb, const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
-  if (PRUNE) wide_step<COUNT, LDS>(P, sc, stack, lane, o, d, rb, sg, all_safe, best_t, cur, sp, cn);
+  if (PRUNE) wide_step<ANY, COUNT, LDS>(P, sc, stack, lane, o, d, rb, sg, all_safe, best_t, cur, sp, cn);
   else node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
 }
 
@@ -570,7 +591,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
         if (at_node >= at_leaf) {
           if (cur >= 0) {
             DIV_COUNT(cn, ANY ? 2 : 0);
-            inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
+            inner_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
           }
         } else if (cur < 0 && cur != STOP) {
           DIV_COUNT(cn, ANY ? 3 : 1);
@@ -584,7 +605,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       while (cur != STOP) {
         while (cur >= 0) {
           DIV_COUNT(cn, ANY ? 2 : 0);
-          inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
+          inner_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
         }
         if (cur != STOP) {
           DIV_COUNT(cn, ANY ? 3 : 1);
@@ -726,7 +747,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
     if (at_node >= at_leaf) {
       if (cur >= 0) {
         DIV_COUNT(cn, 2);
-        inner_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, tlimit, cur, sp, cn);
+        inner_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, tlimit, cur, sp, cn);
       }
     } else if (cur < 0 && cur != STOP) {
       DIV_COUNT(cn, 3);
