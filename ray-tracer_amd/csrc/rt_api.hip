@@ -37,6 +37,7 @@ struct rt_ctx {
   size_t stage_cap = 0;
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
+  float box_absmax = 0.0f;  // largest |coordinate| of any node box
   int n_wnode_recs = 0, wide_stack = 0;  // wide records; most stack entries a wide traversal can hold at once
   // refit (rt_refit_async): which object a primitive record came from, which binary record and side a
   // wide slot copies, and the binary records bottom-up by depth; kept on the host by rt_upload_scene,
@@ -657,6 +658,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.spp = c->spp;
   p.has_root = c->has_root;
   p.boxes_safe = c->boxes_safe;
+  p.box_absmax = c->box_absmax;
   p.W = cam.img_w;
   p.H = cam.img_h;
   p.max_depth = cam.max_depth;
@@ -999,11 +1001,13 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   c->has_root = sc->n_nodes > 0;
   c->tree_depth = rp.max_depth;
   c->boxes_safe = 1;
+  c->box_absmax = 0.0f;
   for (int i = 0; i < sc->n_nodes && c->boxes_safe; ++i) {
     const float *b = &sc->nodes[i].xmin;
     for (int k = 0; k < 6; ++k) {
       float a = std::fabs(b[k]);
       if (!(b[k] == 0.0f || (a >= 1.4551915228366852e-11f && a <= 5.764607523034235e17f))) c->boxes_safe = 0;
+      if (a > c->box_absmax) c->box_absmax = a;
     }
     if (!(b[0] <= b[1] && b[2] <= b[3] && b[4] <= b[5])) c->boxes_safe = 0;  // min <= max (entry/exit form)
   }
@@ -1085,7 +1089,9 @@ int rt_refit_async(rt_ctx *c, const rt_sphere *spheres, int32_t n_spheres, const
   // the exact-reciprocal box path needs every box coordinate 0 or in [2^-36, 2^59] and min <= max:
   // box planes are object coordinates (triangles) or centre -+ radius (spheres)
   c->boxes_safe = 1;
-  auto ok = [](float v) {
+  c->box_absmax = 0.0f;
+  auto ok = [c](float v) {
+    if (std::fabs(v) > c->box_absmax) c->box_absmax = std::fabs(v);
     float a = std::fabs(v);
     return v == 0.0f || (a >= 1.4551915228366852e-11f && a <= 5.764607523034235e17f);
   };

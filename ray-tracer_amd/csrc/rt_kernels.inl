@@ -300,34 +300,53 @@ DEVI void cswap(float &ka, int &ra, float &kb, int &rb) {
 // box test on the way down may err on the side of "hit": it costs 6 fused multiply-adds per box
 // against a per-ray reciprocal, no divisions and no corrections.
 //
-// Per ray: r~ = v_rcp_f32(d) (1 ulp), or~ = RN(o * r~).  Slab distance t~ = RN(c * r~ - or~) against
-// the reference's t = RN(RN(c - o) / d):  |t~ - t| <= 5.2 u |t~| + 1.02 u |or~|  (u = 2^-24: the
-// reciprocal 2 u, the product rounding inside or~, the final rounding, and t's own two roundings;
-// the cancellation c * r~ - or~ is exact inside the FMA).  With E~ = max of the three entries and
-// X~ = min of the three exits:  reference accepts (E <= X)  =>  E~ - X~ <= 5.2 u (|E~| + |X~|) +
-// 2.04 u max |or~|  <  thr := 2^-21 (|E~| + |X~|) + 2^-22 max |or~|.  A box is skipped only when
-// E~ - X~ > thr; range pruning uses E~ - thr and X~ + thr.  No overflow or NaN on this path:
-// |d| in [2^-40, 2^40], |o| and box coordinates <= 2^59 (other rays and scenes take the
-// plain-division path below, which is exact at every node).
+// Per ray and axis: r~ = v_rcp_f32(d) (1 ulp), or~ = RN(o * r~); a slab distance is one FMA,
+// t~ = RN(c * r~ - or~), against the reference's t = RN(RN(c - o) / d).  With tau = (c - o) / d:
+// the reciprocal (2 u), the rounding inside or~ (u |or~|), the final rounding (u) and t's own two
+// roundings (2.1 u |tau|) give  |t~ - t| <= 5.2 u |t~| + 1.02 u |or~|   (u = 2^-24; the cancellation
+// c * r~ - or~ is exact inside the FMA).  Two ways to stay on the safe side of that, E~ = max of the
+// three entries, X~ = min of the three exits:
+//  * scenes held in LDS (few node visits per ray: the per-ray set-up counts): the reference
+//    accepting (E <= X) implies E~ - X~ <= 5.2 u (|E~| + |X~|) + 2.04 u max |or~| <
+//    thr := 2^-21 (|E~| + |X~|) + 2^-22 max |or~|; a box is skipped only when E~ - X~ > thr, range
+//    pruning uses E~ - thr and X~ + thr;
+//  * scenes in memory (tens of node visits per ray): the slop is folded into the FMA's addend once
+//    per ray.  delta = 2^-20 (S + |o|) |r~| per axis, S = the largest |coordinate| of any box of the
+//    scene; entries are RN(c * r~ + a0), a0 = RN(-or~ - delta), exits RN(c * r~ + a1), a1 =
+//    RN(-or~ + delta).  |tau| <= (S + |o|) |1/d|, the addend's own rounding adds u (|or~| + delta):
+//    all errors together stay below 7.3 u (S + |o|) |r~| + u delta < delta = 16 u (S + |o|) |r~|, so
+//    every computed entry is <= the reference's and every computed exit >= the reference's, and
+//    the reference accepting implies E~ <= X~: 6 FMAs, max3, min3 and three comparisons per box.
+// No overflow or NaN on this path: |d| in [2^-40, 2^40], |o| and box coordinates <= 2^59 (other
+// rays and scenes take the plain-division path below, which is exact at every node).
 struct RayBox {
-  float rx, ry, rz;  // ~ 1 / d
-  float ox, oy, oz;  // RN(o * r~)
-  float b0;          // 2^-22 max |or~|
-  bool ok;           // the conservative path is valid for this ray
+  float rx, ry, rz;     // ~ 1 / d
+  float nx, ny, nz;     // addend of the near planes: -(o * r~) [- delta]
+  float fx, fy, fz;     // addend of the far planes (scenes in memory): -(o * r~) + delta
+  float b0;             // scenes in LDS: 2^-22 max |or~|
+  bool ok;              // the conservative path is valid for this ray
 };
+template <bool LDS>
 DEVI RayBox make_raybox(const RenderParams &P, V3 o, V3 d) {
   RayBox b;
   b.rx = __builtin_amdgcn_rcpf(d.x);
   b.ry = __builtin_amdgcn_rcpf(d.y);
   b.rz = __builtin_amdgcn_rcpf(d.z);
-#ifdef RT_BOX_SUBMUL
-  b.ox = b.oy = b.oz = b.b0 = 0.0f;
-#else
-  b.ox = o.x * b.rx;
-  b.oy = o.y * b.ry;
-  b.oz = o.z * b.rz;
-  b.b0 = 2.384185791015625e-07f * fmaxf(fmaxf(fabsf(b.ox), fabsf(b.oy)), fabsf(b.oz));
-#endif
+  const float ox = o.x * b.rx, oy = o.y * b.ry, oz = o.z * b.rz;
+  if (LDS) {
+    b.nx = b.fx = -ox;
+    b.ny = b.fy = -oy;
+    b.nz = b.fz = -oz;
+    b.b0 = 2.384185791015625e-07f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+  } else {
+    const float S = P.box_absmax;
+    const float dx = (9.5367431640625e-07f * (S + fabsf(o.x))) * fabsf(b.rx);
+    const float dy = (9.5367431640625e-07f * (S + fabsf(o.y))) * fabsf(b.ry);
+    const float dz = (9.5367431640625e-07f * (S + fabsf(o.z))) * fabsf(b.rz);
+    b.nx = -ox - dx; b.ny = -oy - dy; b.nz = -oz - dz;
+    b.fx = dx - ox;  b.fy = dy - oy;  b.fz = dz - oz;
+    b.b0 = 0.0f;
+  }
   constexpr float DLO = 9.094947017729282e-13f /*2^-40*/, DHI = 1099511627776.0f /*2^40*/,
                   OHI = 5.764607523034235e17f /*2^59*/;
   // (every comparison is false for a NaN)
@@ -373,8 +392,8 @@ DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o
 // unconditional -- a slot above the top is scratch -- so the step has no divergent pushes.
 // all_ok: every lane of the wave is on the conservative path (RayBox::ok); otherwise the whole
 // wave takes plain divisions and the reference's comparisons (exact at every node).
-// A slot without a child holds an inverted box (min = 2^58, max = -2^58): E~ - X~ >= 2^59 |r~|,
-// far beyond thr, so it is never entered on the conservative path.
+// A slot without a child holds an inverted box (min = 2^58, max = -2^58; not counted in S):
+// E~ - X~ is about 2^59 |r~|, far beyond any slop, so it is never entered on the conservative path.
 template <bool ANY, bool COUNT, bool LDS>
 DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
                     const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
@@ -389,31 +408,25 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
   if (all_ok) {
     const float4 nx = np[sg.x], fx = np[sg.x ^ 1], ny = np[2 + sg.y], fy = np[2 + (sg.y ^ 1)], nz = np[4 + sg.z],
                  fz = np[4 + (sg.z ^ 1)];
-#ifdef RT_BOX_SUBMUL
-#define RT_SLABS(C_)                                                                                \
-    const float tx0 = (nx.C_ - o.x) * rb.rx, tx1 = (fx.C_ - o.x) * rb.rx;                           \
-    const float ty0 = (ny.C_ - o.y) * rb.ry, ty1 = (fy.C_ - o.y) * rb.ry;                           \
-    const float tz0 = (nz.C_ - o.z) * rb.rz, tz1 = (fz.C_ - o.z) * rb.rz;
-#else
-#define RT_SLABS(C_)                                                                                                \
-    const float tx0 = __builtin_fmaf(nx.C_, rb.rx, -rb.ox), tx1 = __builtin_fmaf(fx.C_, rb.rx, -rb.ox);             \
-    const float ty0 = __builtin_fmaf(ny.C_, rb.ry, -rb.oy), ty1 = __builtin_fmaf(fy.C_, rb.ry, -rb.oy);             \
-    const float tz0 = __builtin_fmaf(nz.C_, rb.rz, -rb.oz), tz1 = __builtin_fmaf(fz.C_, rb.rz, -rb.oz);
-#endif
-#define RT_WIDE_CHILD(C_, E_, H_)                                                                                   \
-  {                                                                                                                 \
-    RT_SLABS(C_)                                                                                                    \
-    E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                               \
-    const float X_ = fminf(fminf(tx1, ty1), tz1);                                                                   \
-    const float thr = __builtin_fmaf(fabsf(E_) + fabsf(X_), 4.76837158203125e-07f, rb.b0);                          \
-    H_ = (E_ - X_ <= thr) && !(E_ - thr > lim || X_ + thr < BEHIND);                                                \
+#define RT_WIDE_CHILD(C_, E_, H_)                                                                           \
+  {                                                                                                         \
+    const float tx0 = __builtin_fmaf(nx.C_, rb.rx, rb.nx), tx1 = __builtin_fmaf(fx.C_, rb.rx, rb.fx);       \
+    const float ty0 = __builtin_fmaf(ny.C_, rb.ry, rb.ny), ty1 = __builtin_fmaf(fy.C_, rb.ry, rb.fy);       \
+    const float tz0 = __builtin_fmaf(nz.C_, rb.rz, rb.nz), tz1 = __builtin_fmaf(fz.C_, rb.rz, rb.fz);       \
+    E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                       \
+    const float X_ = fminf(fminf(tx1, ty1), tz1);                                                           \
+    if (LDS) {                                                                                              \
+      const float thr = __builtin_fmaf(fabsf(E_) + fabsf(X_), 4.76837158203125e-07f, rb.b0);                \
+      H_ = (E_ - X_ <= thr) && !(E_ - thr > lim || X_ + thr < BEHIND);                                      \
+    } else {                                                                                                \
+      H_ = (E_ <= X_) && !(E_ > lim || X_ < BEHIND);                                                        \
+    }                                                                                                       \
   }
     RT_WIDE_CHILD(x, e0, h0)
     RT_WIDE_CHILD(y, e1, h1)
     RT_WIDE_CHILD(z, e2, h2)
     RT_WIDE_CHILD(w, e3, h3)
 #undef RT_WIDE_CHILD
-#undef RT_SLABS
   } else {
     // plain divisions (a zero / denormal / huge direction component, out-of-range origin or scene);
     // a NaN entry or exit is ignored by max / min and never prunes
@@ -544,15 +557,15 @@ DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, i
 
 // Per-ray constants of the box tests: the exact reciprocals of the reference-visit mode, or the
 // conservative test's (pruned mode); `safe` = this ray may take the mode's fast path.
-template <bool PRUNE>
+template <bool PRUNE, bool LDS>
 DEVI void ray_setup(const RenderParams &P, V3 o, V3 d, RayDiv &rd, RayBox &rb, bool &safe) {
   rd.rx = rd.ry = rd.rz = 1.0f;
   rd.safe = true;
   rb.rx = rb.ry = rb.rz = 1.0f;
-  rb.ox = rb.oy = rb.oz = rb.b0 = 0.0f;
+  rb.nx = rb.ny = rb.nz = rb.fx = rb.fy = rb.fz = rb.b0 = 0.0f;
   rb.ok = true;
   if (PRUNE) {
-    rb = make_raybox(P, o, d);
+    rb = make_raybox<LDS>(P, o, d);
     safe = rb.ok;
   } else {
     rd = make_raydiv(P, o, d);
@@ -570,7 +583,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   RayDiv rd;
   RayBox rb;
   bool safe;
-  ray_setup<PRUNE>(P, o, d, rd, rb, safe);
+  ray_setup<PRUNE, LDS>(P, o, d, rd, rb, safe);
   const RaySign sg = make_sign(d);
   // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
   // denormal direction component, or an out-of-range scene)
@@ -707,7 +720,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   RayDiv rd;
   RayBox rb;
   bool safe;
-  ray_setup<PRUNE>(P, mk(0, 0, 0), mk(1, 1, 1), rd, rb, safe);
+  ray_setup<PRUNE, LDS>(P, mk(0, 0, 0), mk(1, 1, 1), rd, rb, safe);
   RaySign sg = make_sign(d);
   for (;;) {
     const unsigned long long idle = __ballot(cur == STOP);
@@ -734,7 +747,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
                __uint_as_float(pts[2 * 64 + owner]));
         light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
                   tlimit);
-        ray_setup<PRUNE>(P, o, d, rd, rb, safe);
+        ray_setup<PRUNE, LDS>(P, o, d, rd, rb, safe);
         sg = make_sign(d);
         sp = 0;
         cur = 0;
