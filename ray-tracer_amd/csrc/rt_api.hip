@@ -38,6 +38,8 @@ struct rt_ctx {
   int n_lights = 0, has_root = 0, tree_depth = 0, boxes_safe = 0;
   int n_node_recs = 0, n_prim_recs = 0, n_materials = 0;
   float box_absmax = 0.0f;  // largest |coordinate| of any node box
+  bool nested = true;       // every child box lies inside its parent's (what the pruned traversal rests on)
+  float clear_band = 9.5367431640625e-07f;  // leaf_box_clear's band, 2^-20 (RT_DEBUG_CLEAR_BAND: tests force the re-walk)
   int n_wnode_recs = 0, wide_stack = 0;  // wide records; most stack entries a wide traversal can hold at once
   // refit (rt_refit_async): which object a primitive record came from, which binary record and side a
   // wide slot copies, and the binary records bottom-up by depth; kept on the host by rt_upload_scene,
@@ -659,6 +661,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.has_root = c->has_root;
   p.boxes_safe = c->boxes_safe;
   p.box_absmax = c->box_absmax;
+  p.clear_band = c->clear_band;
   p.W = cam.img_w;
   p.H = cam.img_h;
   p.max_depth = cam.max_depth;
@@ -703,7 +706,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.stats = m.stats;
   // pruned traversal walks the wide records (its stack holds up to wide_stack siblings, and the
   // branch-free pushes may write one slot above the top); the reference-visit mode the binary tree
-  const bool prune = !(flags & RT_FLAG_NO_PRUNE);
+  // (a tree whose boxes do not nest -- a child sticking out of its parent -- is walked the
+  //  reference's way, node by node: the pruned traversal's shortcuts rest on the nesting)
+  const bool prune = !(flags & RT_FLAG_NO_PRUNE) && c->nested;
   const int stack_depth = prune ? std::max(4, (c->wide_stack + 1 + 3) & ~3) : c->stack_depth;
   p.stack_depth = stack_depth;
   p.wnodes = c->d_wnodes;
@@ -879,6 +884,7 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REARM_MIN")) c->rearm_min = std::atoi(e);
   if (const char *e = std::getenv("RT_FIVE_WAVES")) c->five_waves_mode = std::atoi(e);
+  if (const char *e = std::getenv("RT_DEBUG_CLEAR_BAND")) c->clear_band = (float)std::atof(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
@@ -1011,6 +1017,18 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     }
     if (!(b[0] <= b[1] && b[2] <= b[3] && b[4] <= b[5])) c->boxes_safe = 0;  // min <= max (entry/exit form)
   }
+  // Do the boxes nest?  (sahBVH's do: nodeBox = surround left right, BoundingVolumeHierarchy.hs:50.)
+  c->nested = true;
+  for (int i = 0; i < sc->n_nodes && c->nested; ++i) {
+    const rt_bvh_node &n = sc->nodes[i];
+    if (n.left < 0) continue;
+    const float *pb = &n.xmin;
+    for (int k = 0; k < 2; ++k) {
+      const float *cb = &sc->nodes[k ? n.right : n.left].xmin;
+      for (int a = 0; a < 3; ++a)
+        if (!(cb[2 * a] >= pb[2 * a] && cb[2 * a + 1] <= pb[2 * a + 1])) c->nested = false;
+    }
+  }
   c->have_scene = true;
   return RT_OK;
 }
@@ -1088,6 +1106,7 @@ int rt_refit_async(rt_ctx *c, const rt_sphere *spheres, int32_t n_spheres, const
   (void)n_bin;
   // the exact-reciprocal box path needs every box coordinate 0 or in [2^-36, 2^59] and min <= max:
   // box planes are object coordinates (triangles) or centre -+ radius (spheres)
+  c->nested = true;   // the refitted boxes are unions of their children's
   c->boxes_safe = 1;
   c->box_absmax = 0.0f;
   auto ok = [c](float v) {

@@ -95,6 +95,7 @@ struct RenderParams {
   int stack_depth, trace_zero_weight;
   int n_packets, groups_per_tile;     // packet = group of whole pixels; n_local_tiles * groups_per_tile
   int px_per_packet, chunks_per_packet;  // max(1, 64 / spp) pixels; ceil(spp / 64) chunks of 64 samples
+  float clear_band;                      // leaf_box_clear: relative band of a clear "yes" (2^-20)
   float box_absmax;                      // S: the largest |coordinate| of any node box (conservative box tests, rt_kernels.inl)
   int boxes_safe, split_refractive;                  // all node-box coordinates are 0 or in [2^-36, 2^59] (exact-reciprocal path)
   int batch_div, packets_per_shard;                   // guided packet batches: left_in_shard / batch_div, clamped to [1,16]

@@ -384,7 +384,7 @@ DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o
   const float mx = fmaxf(ty0, tz0), my = fmaxf(tx0, tz0), mz = fmaxf(tx0, ty0);
   const float E = fmaxf(tx0, mx), X = fminf(fminf(tx1, ty1), tz1);
   const float g = fminf(fminf(tx1 - mx, ty1 - my), tz1 - mz);
-  return g > 9.5367431640625e-07f * (fabsf(E) + fabsf(X));
+  return g > P.clear_band * (fabsf(E) + fabsf(X));
 }
 
 // Four box tests from one wide record, range pruning, then the children that remain go on the

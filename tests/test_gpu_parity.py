@@ -703,3 +703,72 @@ def test_upload_rejects_a_malformed_scene(rt, damage, needle):
         r.set_world(w)   # the context is still good for a well-formed scene
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("name,w,h,rpp", [("bench1", 96, 72, 16), ("bench3", 64, 48, 4), ("mesh:3000", 96, 54, 4)])
+def test_every_traversal_rewalks_on_the_exact_path(rt, oracle, name, w, h, rpp, monkeypatch):
+    """The pruned traversal tests boxes conservatively on the way down and asks once, at the end,
+    whether the reference accepts the winning primitive's leaf box; a ray without a clear "yes"
+    (normally one in a million, a ray grazing a box edge) walks the tree again on the
+    plain-division path.  RT_DEBUG_CLEAR_BAND (read by rt_init) widens the band of "not clear"
+    so far that EVERY traversal that hits something takes that second walk, closest-hit,
+    single-light shadow rays and the shadow-ray pool (mesh: 8 lights) alike: ids, ray counts and
+    the image must not move."""
+    world = make_world(rt, name, w, h, rpp)
+    r = rt.Renderer(0)
+    try:
+        (_, _, plain_st), _ = run_both(rt, oracle, r, world, 11, rt.FLAG_COUNT_TESTS, oracle.FLAG_CULL_ZERO_WEIGHT)
+    finally:
+        r.close()
+    monkeypatch.setenv("RT_DEBUG_CLEAR_BAND", "1e30")
+    r = rt.Renderer(0)
+    try:
+        (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, r, world, 11, 0, oracle.FLAG_CULL_ZERO_WEIGHT)
+        r.set_samples(rt.generate_grids(11, world.width + 10, world.camera.aa))
+        _, _, forced_st = r.render(rt.FLAG_COUNT_TESTS)
+    finally:
+        r.close()
+    # (the knob took effect: the second walks show up in the box-test count)
+    assert forced_st.box_tests > 1.3 * plain_st.box_tests
+    assert int((g_ids != o_ids).sum()) == 0
+    assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+           (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+    check_image(rt, g_rgb, o_rgb)
+
+
+def test_tree_whose_boxes_do_not_nest_is_walked_the_reference_way(rt, oracle):
+    """The pruned traversal's shortcuts (collapsed levels, conservative inner tests) rest on every
+    child box lying inside its parent's, as sahBVH builds them.  A host may hand over any tree: here
+    an inner node of bench1's tree gets a box narrower than its children, so the reference (and the
+    oracle) never looks below it for rays that miss the narrowed box.  rt_upload_scene notices and
+    such a tree is walked node by node; the damage must show (ids differ from the intact scene)
+    and the GPU must agree with the oracle on the damaged tree, bit for bit."""
+    from types import SimpleNamespace
+    w = make_world(rt, "bench1", 96, 72, 4)
+    v = w.scene.view
+    nodes = (rt.BvhNode * v.n_nodes)(*[v.nodes[i] for i in range(v.n_nodes)])
+    # the inner node with the widest box below the root
+    inner = max((i for i in range(1, v.n_nodes) if nodes[i].left >= 0), key=lambda i: nodes[i].xmax - nodes[i].xmin)
+    mid = 0.5 * (nodes[inner].xmin + nodes[inner].xmax)
+    nodes[inner].xmax = mid
+    bad = rt.SceneView(nodes, v.n_nodes, v.leaf_refs, v.n_refs, v.spheres, v.n_spheres, v.triangles, v.n_triangles,
+                       v.materials, v.n_materials, v.lights, v.n_lights)
+    bad._keep = nodes
+    wb = SimpleNamespace(scene=SimpleNamespace(view=bad), camera=w.camera, width=w.width, height=w.height, spp=w.spp)
+    grids = rt.generate_grids(3, w.width + 10, w.camera.aa)
+    r = rt.Renderer(0)
+    try:
+        r.set_world(w)
+        r.set_samples(grids)
+        _, ids_intact, _ = r.render(0, want_hit_ids=True)
+        r.set_world(wb)
+        g_rgb, g_ids, g_st = r.render(0, want_hit_ids=True)
+        r.set_world(w)   # and back: the intact tree is pruned again
+        _, ids_again, _ = r.render(0, want_hit_ids=True)
+    finally:
+        r.close()
+    o_rgb, o_ids, o_st = oracle.render(wb, grids, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != ids_intact).sum()) > 0, "the narrowed box hides nothing: pick another node"
+    assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
+    assert int((ids_again != ids_intact).sum()) == 0
+    check_image(rt, g_rgb, o_rgb)
