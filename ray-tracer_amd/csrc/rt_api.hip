@@ -680,6 +680,22 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     p.ambient[i] = cam.ambient[i];
     p.w_dir[i] = (-cam.view_d) * cam.w[i];  // multiply ww (-vDt) (RayTracer.hs:197-199): f * a.x
   }
+  for (int i = 0; i < 3; ++i) {
+    p.hot[0 + i] = p.eye[i];
+    p.hot[3 + i] = p.u[i];
+    p.hot[6 + i] = p.v[i];
+    p.hot[9 + i] = p.w_dir[i];
+    p.hot[20 + i] = p.ambient[i];
+  }
+  p.hot[12] = p.view_w;
+  p.hot[13] = p.view_h;
+  p.hot[14] = p.half_view_w;
+  p.hot[15] = p.half_view_h;
+  p.hot[16] = p.lens;
+  p.hot[17] = p.half_lens;
+  p.hot[18] = (float)p.W;
+  p.hot[19] = (float)p.H;
+  p.hot[23] = 0.0f;
   p.tile_w = c->tiling.tile_w;
   p.tile_h = c->tiling.tile_h;
   p.tiles_x = c->tiling.tiles_x;
@@ -746,7 +762,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     cfg.lds_scene = true;
   }
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
-  cfg.lds_bytes += cfg.lds_scene_bytes;
+  cfg.lds_bytes += cfg.lds_scene_bytes + HOT_WORDS * 4;   // + the block's copy of RenderParams::hot
   // The 96-VGPR build (five waves per SIMD): small single-light LDS scenes, and only when a wave
   // has many packets to work through -- on a small share of a frame the extra waves only add
   // start-up and queue-drain steps (1/8 of c2: 0.71 -> 0.79 ms; whole frame, pipelined: 2.42 -> 2.36).

@@ -65,6 +65,7 @@ constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
 constexpr int POINT_WORDS = 8 * 64;  // LDS per wave (multi-light builds): x, y, z, s0, s1, occlusion mask of the step's points, hand-out table, per-light masks
 constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr int HOT_WORDS = 64;    // LDS words per block for RenderParams::hot and the first light
 constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)
 
 struct RenderParams {
@@ -80,6 +81,13 @@ struct RenderParams {
   float eye[3], u[3], v[3], w[3], ambient[3];
   float half_view_w, half_view_h, half_lens;  // view_w / 2, view_h / 2, lens / 2 (IEEE, host)
   float w_dir[3];                             // (-view_d) * w, the camera's w term of getRay (host, same products)
+  // The per-frame constants the step loop uses as VECTOR operands, copied to LDS once per block and
+  // read from there (kept in scalar registers they crowd out the loop's own scalar state, which
+  // the compiler then parks in vector-register lanes: two VALU moves per use):
+  //   [0..2] eye [3..5] u [6..8] v [9..11] w_dir [12] view_w [13] view_h [14] half_view_w
+  //   [15] half_view_h [16] lens [17] half_lens [18] W [19] H (as floats) [20..22] ambient
+  // The LDS copy continues with [32..43] the first light (single-light builds).
+  float hot[24];
   // tiling / partition
   int tile_w, tile_h, tiles_x, tile_samples;
   int rank, nranks, n_local_tiles, compact;

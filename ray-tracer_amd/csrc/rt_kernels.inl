@@ -644,8 +644,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
 }
 
 // The sampled point on light li and the shadow ray towards it (getDirectColor :96-100).
-DEVI void light_ray(const RenderParams &P, int li, V3 pt, float s0, float s1, V3 &l_dir, float &max_d) {
-  const float *Lp = P.lights + (size_t)li * 12;
+DEVI void light_ray(const float *Lp, V3 pt, float s0, float s1, V3 &l_dir, float &max_d) {
   V3 l_a = ld3(Lp + 3), l_b = ld3(Lp + 6);
   V3 l_pt = add(ld3(Lp + 0), add(mk(l_a.x * s0, l_a.y * s0, l_a.z * s0),
                                  mk(l_b.x * s1, l_b.y * s1, l_b.z * s1)));  // :96
@@ -745,7 +744,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
         bit = cl;
         o = mk(__uint_as_float(pts[0 * 64 + owner]), __uint_as_float(pts[1 * 64 + owner]),
                __uint_as_float(pts[2 * 64 + owner]));
-        light_ray(P, lo + bit, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
+        light_ray(P.lights + (size_t)(lo + bit) * 12, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
                   tlimit);
         ray_setup<PRUNE, LDS>(P, o, d, rd, rb, safe);
         sg = make_sign(d);
@@ -798,9 +797,10 @@ DEVI void orthonormal(V3 w, V3 &u, V3 &v) {
 }
 
 // getRay (RayTracer.hs:183-205)
-DEVI void get_ray(const RenderParams &P, float i, float j, float r1, float r2, V3 &base, V3 &dirn) {
-  float lens = P.lens;
-  V3 eye = ld3(P.eye), u = ld3(P.u), v = ld3(P.v);
+// C: the camera constants in RenderParams::hot order (the block's LDS copy, or the kernel argument)
+DEVI void get_ray(const float *C, float i, float j, float r1, float r2, V3 &base, V3 &dirn) {
+  float lens = C[16];
+  V3 eye = ld3(C + 0), u = ld3(C + 3), v = ld3(C + 6);
   if (lens == 0) {
     // pinhole: ru = u * (r1 * 0) - u * (0 / 2) and rv likewise are +0 per component (x * 0 - x * 0
     // for finite x; a negative r1 could make it -0, which eye + (ru + rv) absorbs the same way
@@ -808,18 +808,18 @@ DEVI void get_ray(const RenderParams &P, float i, float j, float r1, float r2, V
     // base = eye + 0: 3 additions for 24 operations
     base = add(eye, mk(0.0f, 0.0f, 0.0f));
   } else {
-    float r1l = r1 * lens, r2l = r2 * lens, l2 = P.half_lens;  // lens / 2, divided on the host
+    float r1l = r1 * lens, r2l = r2 * lens, l2 = C[17];  // lens / 2, divided on the host
     V3 ru = subt(mk(u.x * r1l, u.y * r1l, u.z * r1l), mk(u.x * l2, u.y * l2, u.z * l2));
     V3 rv = subt(mk(v.x * r2l, v.y * r2l, v.z * r2l), mk(v.x * l2, v.y * l2, v.z * l2));
     base = add(eye, add(ru, rv));
   }
-  float vWd = P.view_w, vHt = P.view_h;
-  float iWd = (float)P.W, iHt = (float)P.H;
-  float u_world = i * vWd / iWd - P.half_view_w;  // vWd / 2.0 and vHt / 2.0: same IEEE quotients,
-  float v_world = j * vHt / iHt - P.half_view_h;  // formed once on the host
+  float vWd = C[12], vHt = C[13];
+  float iWd = C[18], iHt = C[19];
+  float u_world = i * vWd / iWd - C[14];  // vWd / 2.0 and vHt / 2.0: same IEEE quotients,
+  float v_world = j * vHt / iHt - C[15];  // formed once on the host
   V3 u_dir = multiply(u, u_world);
   V3 v_dir = multiply(v, v_world);
-  V3 w_dir = ld3(P.w_dir);  // multiply w (-vDt), formed once on the host (the same three products)
+  V3 w_dir = ld3(C + 9);  // multiply w (-vDt), formed once on the host (the same three products)
   V3 dir = add(w_dir, add(u_dir, v_dir));
   V3 fdir = subt(add(dir, eye), base);
   dirn = normalize(fdir);
@@ -1030,9 +1030,20 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     if (PRUNE)
       for (int i = threadIdx.x; i < P.n_prim_recs * 2; i += 64 * WPB) dst[P.lds_leafbox_base + i] = P.leafbox[i];
     for (int i = threadIdx.x; i < P.n_materials * MAT_F; i += 64 * WPB) lds[rec_words + i] = __float_as_uint(P.materials[i]);
+    if (threadIdx.x < 24) lds[scene_words + threadIdx.x] = __float_as_uint(P.hot[threadIdx.x]);
+    if (threadIdx.x >= 32 && threadIdx.x < 44 && P.n_lights > 0)
+      lds[scene_words + threadIdx.x] = __float_as_uint(P.lights[threadIdx.x - 32]);
     __syncthreads();
   }
-  unsigned *stack = lds + scene_words + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
+  // the block's copy of the per-frame vector constants and of the first light (rt_device.h)
+  const float *hotL = reinterpret_cast<const float *>(lds + scene_words);
+  if (!LDS) {
+    if (threadIdx.x < 24) lds[scene_words + threadIdx.x] = __float_as_uint(P.hot[threadIdx.x]);
+    if (threadIdx.x >= 32 && threadIdx.x < 44 && P.n_lights > 0)
+      lds[scene_words + threadIdx.x] = __float_as_uint(P.lights[threadIdx.x - 32]);
+    __syncthreads();
+  }
+  unsigned *stack = lds + scene_words + HOT_WORDS + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
   unsigned *pts = stack + P.stack_depth * 64;  // shaded points of the step (shadow_lights; MLIGHT builds)
   unsigned *cnt = pts + P.point_words;           // cnt[L], L = 2..max_depth : rays queued at level L
 
@@ -1127,7 +1138,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         const unsigned grid = kpix - fdiv(kpix, P.fd_n_grids) * (unsigned)P.n_grids;  // kpix mod n_grids
         const float *F = P.f6 + ((size_t)grid * (size_t)P.spp + smp) * 6;
         float fi = (float)px, fj = (float)(P.H - 1 - py);
-        get_ray(P, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
+        get_ray(hotL, fi + F[0], fj + F[1], F[2], F[3], o, d);  // colorPixel :47-51
         s0 = F[4];
         s1 = F[5];
       }
@@ -1211,7 +1222,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     // getDirectColor (:81-106).  The reference folds the light list from the right:
     // c1 + (c2 + (... + ambient*diffuse)); iterate the lights backwards to add in
     // exactly that order.
-    if (hit) clr = cmul(ld3(P.ambient), ld3(M + 0));  // :91
+    if (hit) clr = cmul(ld3(hotL + 20), ld3(M + 0));  // :91
     const bool cull_unlit = !P.trace_zero_weight;
     if (MLIGHT) {
       // several lights (the host picks this build for them): which lights matter to the point,
@@ -1225,7 +1236,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
             for (int li = hi - 1; li >= lo; --li) {
               V3 l_dir;
               float max_d;
-              light_ray(P, li, pt, s0, s1, l_dir, max_d);
+              light_ray(P.lights + (size_t)li * 12, pt, s0, s1, l_dir, max_d);
               if (!light_matters(l_dir, n, v, M[6])) need &= ~(1u << (li - lo));
             }
         }
@@ -1251,7 +1262,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
           if ((lit >> (li - lo)) & 1u) {
             V3 l_dir;
             float max_d;
-            light_ray(P, li, pt, s0, s1, l_dir, max_d);
+            light_ray(P.lights + (size_t)li * 12, pt, s0, s1, l_dir, max_d);
             V3 l_c = ld3(P.lights + (size_t)li * 12 + 9);
             float s = hs_max(0.0f, dot(l_dir, n));
             V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
@@ -1264,9 +1275,11 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       }
     } else
     for (int li = P.n_lights - 1; li >= 0; --li) {
+      // (this build is chosen for scenes with at most one light: light 0 has a copy in LDS)
+      const float *Lp = li == 0 ? hotL + 32 : P.lights + (size_t)li * 12;
       V3 l_dir;
       float max_d;
-      light_ray(P, li, pt, s0, s1, l_dir, max_d);
+      light_ray(Lp, pt, s0, s1, l_dir, max_d);
       // (the half vector is only formed here for the few lanes whose light is behind the surface;
       //  nothing but `need` stays live across the traversal)
       bool need = hit;
@@ -1278,7 +1291,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       PH_MARK(3);
       n_shadow += __popcll(__ballot(need));
       if (need && sprim < 0) {
-        V3 l_c = ld3(P.lights + (size_t)li * 12 + 9);
+        V3 l_c = ld3(Lp + 9);
         float s = hs_max(0.0f, dot(l_dir, n));
         V3 diffuse_c = cscale(cmul(ld3(M + 0), l_c), s);
         V3 h = normalize(add(v, l_dir));
@@ -1551,7 +1564,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
     if (inside) {
       float fi = (float)px + (two ? 0.25f + 0.5f * (float)(sub & 1) : 0.5f);
       float fj = (float)(P.H - 1 - py) + (two ? 0.25f + 0.5f * (float)(sub >> 1) : 0.5f);
-      get_ray(P, fi, fj, 0.5f, 0.5f, o, d);
+      get_ray(P.hot, fi, fj, 0.5f, 0.5f, o, d);
     }
     float t;
     int p;
