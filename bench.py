@@ -28,6 +28,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Every context renders on its own stream and the gather / assembly run on two more: give each its
+# own hardware queue (HIP's default of 4 makes a fifth stream share one and serialise with it).
+# Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -147,7 +152,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--flags", type=int, default=0, help="rt_render flags (1 = FMA build)")
-    ap.add_argument("--frames-in-flight", type=int, default=3)
+    ap.add_argument("--frames-in-flight", type=int, default=4)
     ap.add_argument("--share-gpu", default="auto", choices=["auto", "yes", "no"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",

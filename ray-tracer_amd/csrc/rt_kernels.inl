@@ -1091,6 +1091,13 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     level = wave_uniform(level);
     if (level == 0) break;
     ++n_steps;
+#ifdef RT_WAVE_PRIO
+    // A frame ends on a few deep ray trees (a glass packet: tens of DEPENDENT steps on one wave).
+    // Waves that are out of packets, or that run a bounce level, are the ones the frame waits for:
+    // the SIMD's arbiter takes their instructions first.
+    if (cur_packet < 0 || level >= RT_WAVE_PRIO) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     PH_MARK(6);
 
     // ---- obtain 64 (or fewer) rays -------------------------------------------------
