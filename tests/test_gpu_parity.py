@@ -772,3 +772,70 @@ def test_tree_whose_boxes_do_not_nest_is_walked_the_reference_way(rt, oracle):
     assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
     assert int((ids_again != ids_intact).sum()) == 0
     check_image(rt, g_rgb, o_rgb)
+
+
+def _scaled_world(rt, w, k):
+    """The world with every length multiplied by 2**k (exact in floating point): objects, boxes,
+    lights, eye, view rectangle and distance, lens."""
+    import copy
+    from types import SimpleNamespace
+    s = float(2.0 ** k)
+    v = w.scene.view
+    nodes = (rt.BvhNode * max(1, v.n_nodes))(*[v.nodes[i] for i in range(v.n_nodes)])
+    for n in nodes:
+        for f in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
+            setattr(n, f, getattr(n, f) * s)
+    sph = (rt.Sphere * max(1, v.n_spheres))(*[v.spheres[i] for i in range(v.n_spheres)])
+    for p in sph:
+        for a in range(3):
+            p.center[a] *= s
+        p.radius *= s
+    tri = (rt.Triangle * max(1, v.n_triangles))(*[v.triangles[i] for i in range(v.n_triangles)])
+    for t in tri:
+        for a in range(3):
+            t.a[a] *= s
+            t.b[a] *= s
+            t.c[a] *= s
+    lights = (rt.Light * max(1, v.n_lights))(*[v.lights[i] for i in range(v.n_lights)])
+    for l in lights:
+        for a in range(3):
+            l.corner[a] *= s
+            l.edge_a[a] *= s
+            l.edge_b[a] *= s
+    view = rt.SceneView(nodes, v.n_nodes, v.leaf_refs, v.n_refs, sph, v.n_spheres, tri, v.n_triangles,
+                        v.materials, v.n_materials, lights, v.n_lights)
+    view._keep = (nodes, sph, tri, lights)
+    cam = copy.copy(w.camera)
+    for a in range(3):
+        cam.eye[a] *= s
+    cam.view_w *= s
+    cam.view_h *= s
+    cam.view_d *= s
+    cam.lens *= s
+    return SimpleNamespace(scene=SimpleNamespace(view=view), camera=cam, width=w.width, height=w.height, spp=w.spp)
+
+
+@pytest.mark.parametrize("name,k", [("bench1", 40), ("bench1", -20), ("bench1", -24), ("bench4", 30), ("mesh:3000", 35),
+                                    ("mesh:3000", -23)])
+def test_scaled_scenes_keep_their_hit_ids(rt, oracle, name, k):
+    """The conservative box tests carry an error budget in absolute and relative terms (per-ray slop
+    from |o / d| and, for scenes in memory, from the scene's largest coordinate).  Scaling every
+    length by a power of two is exact, so the scaled scene must give the oracle's ids, counts and
+    image at any magnitude the arithmetic admits: coordinates near 2^45 and near 2^-22 (much smaller
+    and every hit distance falls under the reference's t > 1e-8 threshold, RayTracer.hs:238)."""
+    w = make_world(rt, name, 80, 60, 4, lens=0.05 if name == "bench4" else 0.0)
+    ws = _scaled_world(rt, w, k)
+    grids = rt.generate_grids(21, w.width + 10, w.camera.aa)
+    r = rt.Renderer(0)
+    try:
+        r.set_world(ws)
+        r.set_samples(grids)
+        g_rgb, g_ids, g_st = r.render(0, want_hit_ids=True)
+    finally:
+        r.close()
+    o_rgb, o_ids, o_st = oracle.render(ws, grids, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0
+    assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+           (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+    assert g_st.primary_hits > 0.3 * g_st.rays_primary      # the scaled camera still sees the scene
+    check_image(rt, g_rgb, o_rgb)
