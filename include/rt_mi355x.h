@@ -138,7 +138,11 @@ typedef struct rt_camera {
  * counted in rt_stats. */
 #define RT_FLAG_TRACE_ZERO_WEIGHT 0x2u
 /* Visit every node whose ancestors pass hitsBox, like hitBVH
- * (src/RayTracer.hs:404-412): no front-to-back order, no t-range pruning. */
+ * (src/RayTracer.hs:404-412): no front-to-back order, no t-range pruning.
+ * Without this flag the traversal is ordered and pruned and tests the inner boxes
+ * conservatively; it returns the same hits as long as every child box lies inside its
+ * parent's (sahBVH's do: BoundingVolumeHierarchy.hs:50).  rt_upload_scene checks that and
+ * walks a tree whose boxes do not nest as if this flag were set. */
 #define RT_FLAG_NO_PRUNE       0x4u
 /* Count box / sphere / triangle tests (slower kernels; for roofline numbers). */
 #define RT_FLAG_COUNT_TESTS    0x8u
