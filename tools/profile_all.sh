@@ -14,7 +14,6 @@ mkdir -p "$S" profiles
 for w in $WL; do
   echo "== $w"
   extra="--no-cpu-baseline"; [ "$w" = c2 ] && extra=""
-  timeout -k 10 300 python bench.py --workload $w $extra > "$S/${w}_bench.json" 2> "$S/${w}_bench.err" || { echo "bench $w failed"; tail -5 "$S/${w}_bench.err"; exit 1; }
   rm -rf "$S/${w}_stats"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/${w}_stats" -- python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > "$S/${w}_stats.log" 2>&1 || { echo "rocprof stats $w failed"; tail -5 "$S/${w}_stats.log"; exit 1; }
   find "$S/${w}_stats" -name '*kernel_stats.csv' -exec cp {} "$S/${w}_kernel_stats.csv" \;
@@ -22,6 +21,9 @@ for w in $WL; do
   bash tools/prof_pmc.sh "$S/pmc_$w" --workload $w --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 > "$S/${w}_pmc.log" 2>&1 || { echo "pmc $w failed"; tail -5 "$S/${w}_pmc.log"; exit 1; }
   bash tools/prof_pmc2.sh "$S/pmc_$w" --workload $w --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 >> "$S/${w}_pmc.log" 2>&1 || { echo "pmc2 $w failed"; tail -5 "$S/${w}_pmc.log"; exit 1; }
   python3 tools/pmc_summary.py "$S/pmc_$w" > "$S/${w}_pmc.txt"
+  # the bench line last: its roofline.traffic is read from THIS run's counter pass
+  cp "$S/${w}_pmc.txt" "profiles/${TAG}_${w}_pmc.txt"
+  timeout -k 10 300 python bench.py --workload $w $extra > "$S/${w}_bench.json" 2> "$S/${w}_bench.err" || { echo "bench $w failed"; tail -5 "$S/${w}_bench.err"; exit 1; }
   head -c 300 "$S/${w}_bench.json"; echo
 done
 if echo "$WL" | grep -qw c2; then
