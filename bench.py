@@ -29,9 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Every context renders on its own stream and the gather / assembly run on two more: give each its
-# own hardware queue (HIP's default of 4 makes a fifth stream share one and serialise with it).
+# own hardware queue (HIP's default of 4 makes a fifth stream share one and serialise with it; up to
+# six contexts, two streams of the collective path, torch's own).
 # Must be set before the runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -152,7 +154,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--flags", type=int, default=0, help="rt_render flags (1 = FMA build)")
-    ap.add_argument("--frames-in-flight", type=int, default=4)
+    ap.add_argument("--frames-in-flight", type=int, default=6)
     ap.add_argument("--share-gpu", default="auto", choices=["auto", "yes", "no"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",

@@ -1790,7 +1790,8 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   if (cfg.ev_k1) (void)hipEventRecord(cfg.ev_k1, s);
   size_t total = (size_t)p.n_local_tiles * p.tile_w * p.tile_h;
   if (total) {
-    int grid = (int)((total + 255) / 256);
+    // eight pixels per thread: a small grid gets its wave slots sooner beside other contexts' persistent waves
+    int grid = (int)((total + 2047) / 2048);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, s, p);
   }

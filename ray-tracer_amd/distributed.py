@@ -130,7 +130,12 @@ class DistributedFrame:
                                device=self.device) for _ in range(self.depth)]
         candidates = [(1, 1)]
         for f in range(2, self.depth + 1):
-            candidates += [(f, 1), (f, f - 1), (f, f)] if f > 2 else [(f, 1), (f, f)]
+            # (three and more whole-GPU grids in flight never won anywhere: not timed)
+            candidates += [(f, f - 1), (f, f)] if f > 2 else [(f, 1), (f, f)]
+        if self.depth >= 4:
+            # headroom: the contexts' persistent waves leave a fifth of the wave slots to the small
+            # kernels between the frames (probe, order, resolve), which otherwise queue for slots
+            candidates += [(self.depth, self.depth + 1)]
         best = None
         for depth, div in candidates:
             for r in self.renderers:
