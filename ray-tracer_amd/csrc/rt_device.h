@@ -42,10 +42,13 @@ constexpr int PRIM_F4 = 4;
 //   f4[6] the 4 child refs (as in the binary record; REF_NONE = no such child, with an inverted box)
 // so that a ray whose direction sign on an axis is s reads its NEAR planes at f4[2a + s] and its
 // FAR planes at f4[2a + (s ^ 1)]: hitsBox's six sign selects per box (BoundingVolumeHierarchy.hs:
-// 194-199) become three per-ray address offsets.  Every primitive whose leaf box passes hitsBox is
-// still tested and no other: on the exact-quotient path a box's test implies its ancestors'
-// (monotone rounding), so skipping the collapsed levels' own boxes changes nothing; the closest hit
-// is order-independent under the total order of the tie rule.  Record 0 is the root.
+// 194-199) become three per-ray address offsets.  In the reference's arithmetic a box's verdict
+// implies its ancestors' (their planes are min / max of the children's, rounding is monotone), so
+// the primitives the reference tests are those whose LEAF box hitsBox accepts: skipping the
+// collapsed levels' own boxes changes nothing, the inner tests may err towards "hit", and the leaf
+// box of the primitive that wins is what gets the exact question (rt_kernels.inl, RayBox /
+// leaf_box_clear; leaf boxes: RenderParams::leafbox).  The closest hit is order-independent under
+// the total order of the tie rule.  Record 0 is the root.
 constexpr int WNODE_F4 = 8;
 constexpr int LDS_WNODE_F4 = 9;  // LDS stride of a wide record: 36 dwords, walks all sixteen 4-bank groups
 constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)

@@ -628,9 +628,6 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
     }
     // (waves on the plain-division path have tested every box exactly on the way down)
     if (!PRUNE || !all_safe) break;
-#ifdef RT_NO_VERIFY
-    break;
-#endif
     const bool bad = best_p >= 0 && !leaf_box_clear<LDS>(P, sc, best_p, o, d, rb);
     if (__ballot(bad) == 0ull) break;
     all_safe = false;
