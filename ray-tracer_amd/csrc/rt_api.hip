@@ -734,7 +734,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   LaunchCfg cfg{};
   cfg.block = 64 * WAVES_PER_BLOCK;
   cfg.mlight = c->n_lights > 1;
-  p.point_words = cfg.mlight ? POINT_WORDS : 0;
+  p.point_words = point_words_for(c->n_lights);
   cfg.lds_bytes = lds_bytes_for(stack_depth, p.point_words);
   cfg.ev_k0 = c->timing ? c->evk0 : nullptr;
   cfg.ev_k1 = c->timing ? c->evk1 : nullptr;
@@ -972,7 +972,15 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   up.add(&c->d_nodes, &c->cap_nodes, rp.nodes.data(), rp.nodes.size() * 4);
   up.add(&c->d_prims, &c->cap_prims, rp.prims.data(), rp.prims.size() * 4);
   WideBuild wb{rp.nodes};
-  wb.cap = std::max(27, rp.max_depth);
+  // The deepest traversal stack with which four 4-wave blocks still share a CU's 160 KB of LDS
+  // beside the block's constants and, with several lights, the shadow-ray pool (c3: 31 entries):
+  // the collapse widens nodes up to that need and no further (a wider tree is a faster tree, c3
+  // 5.15 ms at a cap of 22, 4.40 at 27; a third block per CU less costs more than it gains).
+  {
+    const int per_wave = ((160 * 1024 / 4) - HOT_WORDS * 4) / WAVES_PER_BLOCK - (point_words_for(sc->n_lights) + 32) * 4;
+    const int depth_max = std::min(40, (per_wave / 256) & ~3);   // stack_depth is a multiple of 4 and holds one scratch slot
+    wb.cap = std::max(std::max(3, depth_max - 1), rp.max_depth);
+  }
   wb.height.assign(rp.nodes.size() / 16, -1);
   if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
   else {

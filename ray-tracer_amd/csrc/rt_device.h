@@ -65,7 +65,9 @@ constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS s
 constexpr int MAT_F = 20;
 constexpr int QCAP = 192;       // ray-queue capacity per level: 63 left over + 2*64 pushed
 constexpr int QFIELDS = 12;     // o.xyz d.xyz w.rgb s0 s1 slot
-constexpr int POINT_WORDS = 8 * 64;  // LDS per wave (multi-light builds): x, y, z, s0, s1, occlusion mask of the step's points, hand-out table, per-light masks
+// LDS words per wave for the shadow-ray pool (multi-light builds): x, y, z, s0, s1, occlusion mask of
+// the step's points, hand-out table (64 words each), then two mask words per light of a 32-light round
+inline int point_words_for(int n_lights) { return n_lights > 1 ? 7 * 64 + ((2 * (n_lights < 32 ? n_lights : 32) + 3) & ~3) : 0; }
 constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counter array)
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int HOT_WORDS = 64;    // LDS words per block for RenderParams::hot and the first light
@@ -124,7 +126,7 @@ struct RenderParams {
   int n_materials, batch_cap;            // batch_cap: most tickets per request in the cheap classes
   int refr_cap, refl_cap;                // ticket batch caps in the refractive / reflective cost class
   FastDiv fd_groups_per_tile, fd_tiles_x, fd_spp, fd_tile_w, fd_n_grids;  // the hot loop's divisors
-  int point_words;                       // LDS words per wave for the step's shaded points (POINT_WORDS, or 0 with one light)
+  int point_words;                       // LDS words per wave for the step's shaded points (point_words_for; 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
 };
 
