@@ -350,8 +350,8 @@ struct WideBuild {
   std::vector<int> src;           // per wide slot: (binary record << 1) | side whose box it copies, -1 = none
   int max_stack = 0;
   // Most entries the traversal stack may ever hold.  A wide node leaves up to 3 siblings on the
-  // stack per level instead of the binary tree's 1, and the per-lane stacks are LDS: 27 entries
-  // (+1 scratch slot) is what still lets four blocks share a CU beside the shadow-ray pool.  Where a
+  // stack per level instead of the binary tree's 1, and the per-lane stacks are LDS: the cap
+  // (set by rt_upload_scene from the LDS budget) is what still lets four blocks share a CU.  Where a
   // path would exceed the cap the collapse stops early (fewer children per node); a binary
   // continuation needs one entry per remaining level, so cap >= the binary tree's depth suffices.
   int cap = 27;
