@@ -329,6 +329,23 @@ int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t 
  * NULL; at least one of them.  With rgb8_out alone every rank quantises its own tiles and BYTES are
  * gathered.  stats (may be NULL): sums over the ranks; times = the slowest rank's.  Host pointers. */
 int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out, rt_stats *stats);
+/* The two halves of rt_multi_render, for hosts that keep frames in flight.  rt_multi_submit
+ * enqueues the frame on every GPU (render, exchange, assembly, copy to the host pointers) and
+ * returns without waiting; rt_multi_wait blocks until that frame is in rgb_out / rgb8_out (which
+ * must stay valid until then) and returns the statistics.  One rt_multi has one frame in flight:
+ * a host that wants K frames in flight makes K rt_multi on the same devices and goes round them,
+ *     submit(m[0]) submit(m[1]) .. wait(m[0]) submit(m[0]) wait(m[1]) submit(m[1]) ..
+ * -- the tail of a frame is a few deep ray trees, and the next frame's work fills the wave slots
+ * it leaves idle (c2 on one GPU, 8-bit frame delivered to host memory: 2.47 ms per frame one at a
+ * time, 1.74 ms with four in flight on a third of the wave slots each, rt_multi_set_concurrency;
+ * tools/multi_pipeline.py).  The frame travels through pinned staging memory of the library, so
+ * that rt_multi_submit does not wait for it; rt_multi_wait copies it to the caller's pointers.
+ * Frames do not depend on how many are in flight.  No counterpart in the reference. */
+int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out);
+int rt_multi_wait(rt_multi *m, rt_stats *stats);
+/* rt_set_concurrency on every GPU: with K rt_multi in flight, each launching 1/K of the wave slots
+ * is usually the fastest split (the choice never changes a pixel). */
+int rt_multi_set_concurrency(rt_multi *m, int32_t n);
 const char *rt_multi_last_error(rt_multi *m);
 
 #ifdef __cplusplus

@@ -48,6 +48,9 @@ foreign import ccall safe   "rt_multi_upload_scene" c_m_upload   :: Ptr RtMulti 
 foreign import ccall safe   "rt_multi_set_camera"   c_m_camera   :: Ptr RtMulti -> Ptr () -> IO CInt
 foreign import ccall safe   "rt_multi_set_samples"  c_m_samples  :: Ptr RtMulti -> Ptr CFloat -> Int32 -> Int32 -> IO CInt
 foreign import ccall safe   "rt_multi_render"       c_m_render   :: Ptr RtMulti -> Word32 -> Ptr CFloat -> Ptr Word8 -> Ptr () -> IO CInt
+foreign import ccall safe   "rt_multi_submit"       c_m_submit   :: Ptr RtMulti -> Word32 -> Ptr CFloat -> Ptr Word8 -> IO CInt
+foreign import ccall safe   "rt_multi_wait"         c_m_wait     :: Ptr RtMulti -> Ptr () -> IO CInt
+foreign import ccall safe   "rt_multi_set_concurrency" c_m_concurrency :: Ptr RtMulti -> Int32 -> IO CInt
 foreign import ccall unsafe "rt_multi_last_error"   c_m_error    :: Ptr RtMulti -> IO CString
 
 -- ---------------------------------------------------------------------------------------------

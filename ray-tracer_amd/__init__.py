@@ -116,7 +116,7 @@ DEVICE_SYMBOLS = [
     "rt_assemble_async", "rt_collect", "rt_quantize_async", "rt_last_error", "rt_abi_version",
     "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing", "rt_render_static_async",
     "rt_assemble8_async", "rt_multi_init", "rt_multi_shutdown", "rt_multi_upload_scene", "rt_multi_set_camera",
-    "rt_multi_set_samples", "rt_multi_render", "rt_multi_last_error", "rt_refit_async", "rt_multi_refit",
+    "rt_multi_set_samples", "rt_multi_render", "rt_multi_submit", "rt_multi_wait", "rt_multi_set_concurrency", "rt_multi_last_error", "rt_refit_async", "rt_multi_refit",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -234,6 +234,9 @@ def device_lib() -> C.CDLL:
         L.rt_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
         L.rt_multi_set_samples.argtypes = [vp, C.POINTER(f32), i32, i32]
         L.rt_multi_render.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(C.c_uint8), C.POINTER(Stats)]
+        L.rt_multi_submit.argtypes = [vp, u32, C.POINTER(f32), C.POINTER(C.c_uint8)]
+        L.rt_multi_wait.argtypes = [vp, C.POINTER(Stats)]
+        L.rt_multi_set_concurrency.argtypes = [vp, i32]
         L.rt_multi_refit.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32]
         L.rt_multi_last_error.argtypes = [vp]
         L.rt_multi_last_error.restype = C.c_char_p
@@ -638,6 +641,28 @@ class MultiRenderer:
                                              rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_8bit else None,
                                              C.byref(st)), "rt_multi_render")
         return rgb, rgb8, st
+
+    def submit(self, flags: int = 0, want_float: bool = True, want_8bit: bool = False) -> None:
+        """rt_multi_submit: enqueue one frame and return; wait() hands it over.  A host keeps K frames
+        in flight with K MultiRenderers on the same devices."""
+        w = self.world
+        assert w is not None and (want_float or want_8bit)
+        rgb = np.zeros((w.height * w.width, 3), np.float32) if want_float else None
+        rgb8 = np.zeros((w.height * w.width, 3), np.uint8) if want_8bit else None
+        self._check(self.lib.rt_multi_submit(self._h, flags,
+                                             rgb.ctypes.data_as(C.POINTER(f32)) if want_float else None,
+                                             rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_8bit else None),
+                    "rt_multi_submit")
+        self._rgb, self._rgb8 = rgb, rgb8   # (kept alive, and only replaced once the frame is accepted)
+
+    def set_concurrency(self, n: int) -> None:
+        self._check(self.lib.rt_multi_set_concurrency(self._h, n), "rt_multi_set_concurrency")
+
+    def wait(self):
+        """rt_multi_wait: (rgb or None, rgb8 or None, Stats) of the frame submitted last."""
+        st = Stats()
+        self._check(self.lib.rt_multi_wait(self._h, C.byref(st)), "rt_multi_wait")
+        return self._rgb, self._rgb8, st
 
     def close(self) -> None:
         if self._h:

@@ -85,6 +85,14 @@ struct rt_multi {
   size_t cap_stride = 0, cap_pixels = 0;
   std::vector<hipEvent_t> done;          // rank r's tiles are in its buffer
   bool have_cam = false, have_samples = false;
+  bool in_flight = false;                // a frame has been submitted and not yet waited for
+  // pinned staging for the frame on its way to the caller's (pageable) memory: a device-to-host
+  // copy into pageable memory would hold rt_multi_submit until the frame is done
+  float *h_rgb = nullptr;
+  uint8_t *h_rgb8 = nullptr;
+  size_t cap_host = 0;                   // pixels
+  float *out_rgb = nullptr;              // where rt_multi_wait delivers the frame in flight
+  uint8_t *out_rgb8 = nullptr;
   rt_camera cam{};
 };
 
@@ -130,6 +138,11 @@ void free_frame_buffers(rt_multi *m) {
     if (p) (void)hipFree(p);
   m->d_gathered = m->d_rgb = nullptr;
   m->d_gathered8 = m->d_rgb8 = nullptr;
+  if (m->h_rgb) (void)hipHostFree(m->h_rgb);
+  if (m->h_rgb8) (void)hipHostFree(m->h_rgb8);
+  m->h_rgb = nullptr;
+  m->h_rgb8 = nullptr;
+  m->cap_host = 0;
   m->d_tiles.assign(m->n, nullptr);
   m->d_tiles8.assign(m->n, nullptr);
   m->cap_stride = m->cap_pixels = 0;
@@ -156,6 +169,9 @@ int ensure_buffers(rt_multi *m) {
   M_HIP(m, hipMalloc((void **)&m->d_gathered8, std::max<size_t>(1, m->n * stride)));
   M_HIP(m, hipMalloc((void **)&m->d_rgb, std::max<size_t>(1, pixels * 3) * sizeof(float)));
   M_HIP(m, hipMalloc((void **)&m->d_rgb8, std::max<size_t>(1, pixels * 3)));
+  M_HIP(m, hipHostMalloc((void **)&m->h_rgb, std::max<size_t>(1, pixels * 3) * sizeof(float), hipHostMallocDefault));
+  M_HIP(m, hipHostMalloc((void **)&m->h_rgb8, std::max<size_t>(1, pixels * 3), hipHostMallocDefault));
+  m->cap_host = pixels;
   M_HIP(m, hipMemset(m->d_gathered, 0, std::max<size_t>(1, m->n * stride) * sizeof(float)));  // (tile padding is never written)
   m->d_tiles[0] = m->d_gathered;    // rank 0 renders straight into its slice
   m->d_tiles8[0] = m->d_gathered8;
@@ -255,6 +271,12 @@ int rt_multi_set_camera(rt_multi *m, const rt_camera *cam) {
   return RT_OK;
 }
 
+int rt_multi_set_concurrency(rt_multi *m, int32_t n) {
+  if (!m) return RT_ERR_INVALID;
+  for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_concurrency(m->ctx[r], n));
+  return RT_OK;
+}
+
 int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t spp) {
   if (!m || !f6) return RT_ERR_INVALID;
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_samples(m->ctx[r], f6, n_grids, spp));
@@ -262,8 +284,9 @@ int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t 
   return RT_OK;
 }
 
-int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out, rt_stats *stats) {
+int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out) {
   if (!m || (!rgb_out && !rgb8_out)) return RT_ERR_INVALID;
+  if (m->in_flight) return mfail(m, RT_ERR_STATE, "rt_multi_submit: the previous frame has not been waited for (rt_multi_wait)");
   if (!m->have_cam || !m->have_samples) return mfail(m, RT_ERR_STATE, "camera and samples must be set first");
   int rc = ensure_buffers(m);
   if (rc) return rc;
@@ -319,16 +342,26 @@ int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
   const size_t n3 = (size_t)m->cam.img_w * m->cam.img_h * 3;
   if (want8) {
     M_CTX(m, 0, rt_assemble8_async(m->ctx[0], m->d_gathered8, m->n, stride, m->d_rgb8, nullptr));
-    M_HIP(m, hipMemcpyAsync(rgb8_out, m->d_rgb8, n3, hipMemcpyDeviceToHost, m->stream[0]));
+    M_HIP(m, hipMemcpyAsync(m->h_rgb8, m->d_rgb8, n3, hipMemcpyDeviceToHost, m->stream[0]));
   } else {
     M_CTX(m, 0, rt_assemble_async(m->ctx[0], m->d_gathered, m->n, stride, m->d_rgb, nullptr));
-    M_HIP(m, hipMemcpyAsync(rgb_out, m->d_rgb, n3 * sizeof(float), hipMemcpyDeviceToHost, m->stream[0]));
+    M_HIP(m, hipMemcpyAsync(m->h_rgb, m->d_rgb, n3 * sizeof(float), hipMemcpyDeviceToHost, m->stream[0]));
     if (rgb8_out) {
       M_CTX(m, 0, rt_quantize_async(m->ctx[0], m->d_rgb, m->d_rgb8, n3, nullptr));
-      M_HIP(m, hipMemcpyAsync(rgb8_out, m->d_rgb8, n3, hipMemcpyDeviceToHost, m->stream[0]));
+      M_HIP(m, hipMemcpyAsync(m->h_rgb8, m->d_rgb8, n3, hipMemcpyDeviceToHost, m->stream[0]));
     }
   }
-  // 4. wait for every rank; the statistics are the sums over the ranks (times: the slowest)
+  m->out_rgb = rgb_out;
+  m->out_rgb8 = rgb8_out;
+  m->in_flight = true;
+  return RT_OK;
+}
+
+int rt_multi_wait(rt_multi *m, rt_stats *stats) {
+  if (!m) return RT_ERR_INVALID;
+  if (!m->in_flight) return mfail(m, RT_ERR_STATE, "rt_multi_wait: no frame has been submitted");
+  m->in_flight = false;
+  // wait for every rank; the statistics are the sums over the ranks (times: the slowest)
   rt_stats total;
   std::memset(&total, 0, sizeof total);
   for (int r = m->n - 1; r >= 0; --r) {
@@ -349,8 +382,18 @@ int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
     total.ms_kernel = std::max(total.ms_kernel, st.ms_kernel);
     total.ms_launch = std::max(total.ms_launch, st.ms_launch);
   }
+  // (rt_collect has waited for rank 0's stream: the frame is in the staging buffers)
+  const size_t n3 = (size_t)m->cam.img_w * m->cam.img_h * 3;
+  if (m->out_rgb) std::memcpy(m->out_rgb, m->h_rgb, n3 * sizeof(float));
+  if (m->out_rgb8) std::memcpy(m->out_rgb8, m->h_rgb8, n3);
   if (stats) *stats = total;
   return RT_OK;
+}
+
+int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out, rt_stats *stats) {
+  int rc = rt_multi_submit(m, flags, rgb_out, rgb8_out);
+  if (rc) return rc;
+  return rt_multi_wait(m, stats);
 }
 
 }  // extern "C"

@@ -52,6 +52,43 @@ def test_multi_frame_is_bitwise_the_single_context_frame(rt, devices):
         m.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_frames_in_flight_through_submit_and_wait(rt, devices):
+    """rt_multi_submit / rt_multi_wait: K rt_multi on the same devices, gone round by one host
+    thread, keep K frames in flight.  Every frame is bitwise the single-context frame, whatever
+    was in flight beside it; misuse (two submits, a wait without a submit) is an error."""
+    K = 3
+    worlds = [make_world(rt, n, 160, 120, 4) for n in ("bench1", "bench5", "bench2")]
+    grids = [rt.generate_grids(31 + i, 170, w.camera.aa) for i, w in enumerate(worlds)]
+    refs = [single(rt, w, g)[0] for w, g in zip(worlds, grids)]
+    ms = [rt.MultiRenderer(devices) for _ in range(K)]
+    try:
+        for i, m in enumerate(ms):
+            m.set_world(worlds[i])
+            m.set_samples(grids[i])
+        for m in ms:
+            m.submit(0)
+        for rnd in range(4):
+            for i, m in enumerate(ms):
+                rgb, _, st = m.wait()
+                assert np.array_equal(rgb.view(np.uint32), refs[i].view(np.uint32))
+                assert st.rays_primary == 160 * 120 * 4
+                m.submit(0, want_float=(rnd % 2 == 0), want_8bit=True)
+                if rnd % 2 == 1:
+                    with pytest.raises(rt.RtError, match="has not been waited for"):
+                        m.submit(0)
+                    _, rgb8, _ = m.wait()
+                    assert np.array_equal(rgb8, rt.quantize(refs[i]))
+                    m.submit(0)
+        for m in ms:
+            m.wait()
+        with pytest.raises(rt.RtError, match="no frame has been submitted"):
+            ms[0].wait()
+    finally:
+        for m in ms:
+            m.close()
+
+
 def test_multi_reports_errors(rt):
     with pytest.raises(rt.RtError, match="rt_init"):
         rt.MultiRenderer([0, 4711])                    # no such GPU
