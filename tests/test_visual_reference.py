@@ -111,3 +111,102 @@ def test_gpu_reproduces_the_reference_stills(rt, oracle, name):
     assert int((g_ids != o_ids).sum()) == 0 and g_st.rays_total == o_st.rays_total
     d = np.abs(rt.quantize(g_rgb).astype(int) - rt.quantize(o_rgb).astype(int))
     assert d.max() <= 1
+
+
+# ---- the animated sample: geometry of the scene-description path, frame by frame ---------------
+# /root/reference/images/spheres.gif: 100 frames, 800x600, of the sample description `sdl` (three
+# spheres on circles of radius 7, 8 and 6 around a glass sphere, phase t * 3.14 / 50 -- one with the
+# sample's `3.15` in its sine --, eye (15, 2, 15) looking at (-1, -1, -1), view plane 8 x 6 at
+# distance 4).  The frames were shaded by an older material model (separate gloss, per-material
+# ambient), so colours cannot be compared; WHERE the objects are can: tests/golden/
+# ref_spheres_gif_coverage_frameKK_200x150.png hold the object coverage of four frames (fraction of
+# each 4x4 block that is not background).  Ours is the fraction of a pixel's 16 primary rays that hit
+# anything.  The description below states the sample's numbers in our own words (materials are
+# irrelevant to coverage); it goes through parse_scene_description, the expression evaluator,
+# configToWorld / getCam, getRay and the sphere test.  Measured: sum |coverage - ours| is 31-37 pixels
+# of 760-970 (4 %) at t = K + 1 -- the GIF's first frame is t = 1 -- and 3-4 times that one frame
+# earlier or later: bar 6 % of the frame's object area; a frame off by one must fail it.
+SAMPLE_ORBITS = """
+CONFIG
+  EYE {15 2 15}
+  LOOKAT {-1 -1 -1}
+  UP {0 1 0}
+  VIEWPLANE {8 6 4}
+  AMBIENT Color 0.1 0.1 0.1
+END
+LIGHTS
+  Light {50 20 0} Color 0.5 0.5 0.5
+END
+COLORS
+  Color grey = 0.6 0.6 0.6
+  Color black = 0 0 0
+  Color white = 1 1 1
+END
+MATERIAL
+  Material matte = grey grey black 10.0 black 0.0 white 0
+END
+SHAPES
+  Sphere centre = {0 0 0} 3 matte
+  Sphere a = {sin(t*3.14/50)*7 0 cos(t*3.14/50)*7} 1 matte
+  Sphere b = {0 sin(t*3.15/50)*8 cos(t*3.14/50)*8} 1 matte
+  Sphere c = {sin(t*3.14/50)*6 cos(t*3.14/50)*6 0} 1 matte
+  Triangle far1 = {0 20 0} {1 20 0} {1 20 1} matte
+  Triangle far2 = {0 -20 0} {1 -20 0} {1 -20 1} matte
+  Triangle far3 = {-20 0 0} {-20 0 1} {-20 1 1} matte
+END
+"""
+GIF_W, GIF_H = 200, 150
+GIF_FRAMES = (0, 24, 59, 98)
+
+
+def gif_coverage(k):
+    from PIL import Image
+    a = np.asarray(Image.open(os.path.join(HERE, "golden", f"ref_spheres_gif_coverage_frame{k:02d}_{GIF_W}x{GIF_H}.png")))
+    assert a.shape == (GIF_H, GIF_W)
+    return a.astype(np.float64) / 255.0
+
+
+def sample_world(rt, t):
+    import importlib
+    anim = importlib.import_module("ray-tracer_amd.animation")
+    d = anim.parse_scene_description(SAMPLE_ORBITS)
+    cfg = rt.Config(image_width=GIF_W, image_height=GIF_H, reflection_depth=1, anti_aliasing=4)
+    return d.world_at(float(t), cfg)
+
+
+def coverage_of(ids):
+    return (ids.reshape(GIF_H, GIF_W, -1) != 0xFFFFFFFF).mean(axis=2)
+
+
+@pytest.mark.parametrize("k", GIF_FRAMES)
+def test_oracle_puts_the_sample_animation_where_the_reference_gif_has_it(rt, oracle, k):
+    ref = gif_coverage(k)
+    area = ref.sum()
+    dist = {}
+    for t in (k, k + 1, k + 2):
+        w = sample_world(rt, t)
+        grids = rt.generate_grids(3, GIF_W + 10, w.camera.aa)
+        _, ids, _ = oracle.render(w, grids, 0, want_hit_ids=True)
+        dist[t] = float(np.abs(ref - coverage_of(ids)).sum())
+    print(f"frame {k}: object area {area:.0f} px, sum |coverage - ours| at t = k, k+1, k+2: "
+          + ", ".join(f"{dist[t]:.1f}" for t in (k, k + 1, k + 2)))
+    assert dist[k + 1] <= 0.06 * area
+    assert dist[k] > 0.09 * area and dist[k + 2] > 0.09 * area     # one frame off shows
+
+
+@pytest.mark.gpu
+def test_gpu_puts_the_sample_animation_where_the_reference_gif_has_it(rt, oracle):
+    k = 24
+    ref = gif_coverage(k)
+    w = sample_world(rt, k + 1)
+    grids = rt.generate_grids(3, GIF_W + 10, w.camera.aa)
+    r = rt.Renderer(0)
+    try:
+        r.set_world(w)
+        r.set_samples(grids)
+        _, g_ids, _ = r.render(0, want_hit_ids=True)
+    finally:
+        r.close()
+    _, o_ids, _ = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT, want_hit_ids=True)
+    assert int((g_ids != o_ids).sum()) == 0
+    assert float(np.abs(ref - coverage_of(g_ids)).sum()) <= 0.06 * ref.sum()
