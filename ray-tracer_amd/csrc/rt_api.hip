@@ -798,9 +798,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.rearm_min = c->rearm_min > 0 ? std::min(c->rearm_min, 64) : 12;
   p.batch_div = std::max(1, 2 * cfg.grid * wpb / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
-  // <= 1024 blocks, and at least 512 packets per block: with other contexts' persistent waves on the
-  // GPU a small kernel waits for every wave slot it asks for (a rank's share of a frame in flight)
-  p.probe_span = std::max(512, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);
+  p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
   p.probe_blocks = std::max(1, (p.n_packets + p.probe_span - 1) / p.probe_span);
   p.pclass = m.pclass;
   p.block_hist = m.block_hist;
