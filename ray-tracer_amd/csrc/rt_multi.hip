@@ -302,13 +302,19 @@ int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
   // 2. the one exchange step: gather on rank 0
   if (m->use_rccl) {
     M_NCCL(m, m->rccl.GroupStart());
-    for (int r = 1; r < m->n; ++r) {
+    // (a transfer that fails to enqueue must not leave the group open: close it, then report)
+    ncclResult_t bad = ncclSuccess;
+    auto queued = [&](ncclResult_t r) {
+      if (r != ncclSuccess && bad == ncclSuccess) bad = r;
+      return bad == ncclSuccess;
+    };
+    for (int r = 1; r < m->n && bad == ncclSuccess; ++r) {
       if (want8) {
-        M_NCCL(m, m->rccl.Send(m->d_tiles8[r], stride, ncclUint8, 0, m->comm[r], m->stream[r]));
-        M_NCCL(m, m->rccl.Recv(m->d_gathered8 + r * stride, stride, ncclUint8, r, m->comm[0], m->stream[0]));
+        if (queued(m->rccl.Send(m->d_tiles8[r], stride, ncclUint8, 0, m->comm[r], m->stream[r])))
+          (void)queued(m->rccl.Recv(m->d_gathered8 + r * stride, stride, ncclUint8, r, m->comm[0], m->stream[0]));
       } else {
-        M_NCCL(m, m->rccl.Send(m->d_tiles[r], stride, ncclFloat32, 0, m->comm[r], m->stream[r]));
-        M_NCCL(m, m->rccl.Recv(m->d_gathered + r * stride, stride, ncclFloat32, r, m->comm[0], m->stream[0]));
+        if (queued(m->rccl.Send(m->d_tiles[r], stride, ncclFloat32, 0, m->comm[r], m->stream[r])))
+          (void)queued(m->rccl.Recv(m->d_gathered + r * stride, stride, ncclFloat32, r, m->comm[0], m->stream[0]));
       }
     }
     if (m->n == 1) {
@@ -318,12 +324,13 @@ int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
       const ncclDataType_t ty = want8 ? ncclUint8 : ncclFloat32;
       const size_t head = std::min<size_t>({stride, (size_t)m->cam.img_w * m->cam.img_h * 3, (size_t)256});
       void *tmp = want8 ? (void *)m->d_rgb8 : (void *)m->d_rgb;  // scratch: overwritten by the assembly below
-      if (head) {
-        M_NCCL(m, m->rccl.Send(buf, head, ty, 0, m->comm[0], m->stream[0]));
-        M_NCCL(m, m->rccl.Recv(tmp, head, ty, 0, m->comm[0], m->stream[0]));
-      }
+      if (head && queued(m->rccl.Send(buf, head, ty, 0, m->comm[0], m->stream[0])))
+        (void)queued(m->rccl.Recv(tmp, head, ty, 0, m->comm[0], m->stream[0]));
     }
-    M_NCCL(m, m->rccl.GroupEnd());
+    const ncclResult_t closed = m->rccl.GroupEnd();
+    if (bad != ncclSuccess)
+      return mfail(m, RT_ERR_DEVICE, "RCCL gather (send/recv): %s", m->rccl.GetErrorString(bad));
+    M_NCCL(m, closed);
   } else {
     for (int r = 1; r < m->n; ++r) {
       M_HIP(m, hipSetDevice(m->devices[r]));

@@ -839,3 +839,66 @@ def test_scaled_scenes_keep_their_hit_ids(rt, oracle, name, k):
            (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
     assert g_st.primary_hits > 0.3 * g_st.rays_primary      # the scaled camera still sees the scene
     check_image(rt, g_rgb, o_rgb)
+
+
+def _random_soup(rt, seed):
+    """A scene nobody designed: triangles of every shape the tree builder and the box tests can meet
+    (axis-aligned and therefore flat boxes, slivers, points far from the origin, exact duplicates,
+    pairs sharing an edge), spheres that overlap them, every kind of material, one to three area
+    lights, the eye sometimes inside the soup."""
+    rng = np.random.default_rng(seed)
+    names = ["whiteDull", "redDull", "greenShiny", "whiteShiny", "whiteMirror", "glass", "diamond", "blueDull"]
+    mats = [rt.material(m) for m in names]
+    n_tri, n_sph = int(rng.integers(60, 400)), int(rng.integers(0, 12))
+    span = float(rng.choice([1.0, 8.0, 300.0]))
+    tris, spheres = [], []
+    for k in range(n_tri):
+        c = rng.uniform(-span, span, 3)
+        kind = rng.integers(0, 5)
+        e1, e2 = rng.normal(0, 0.6 * span, 3), rng.normal(0, 0.6 * span, 3)
+        if kind == 0:                      # axis-aligned: one coordinate constant -> a flat box
+            ax = int(rng.integers(0, 3))
+            e1[ax] = e2[ax] = 0.0
+        elif kind == 1:                    # sliver
+            e2 = e1 * 1.0001 + rng.normal(0, 1e-4 * span, 3)
+        elif kind == 2 and tris:           # an exact duplicate of an earlier triangle, other material
+            t = tris[int(rng.integers(0, len(tris)))]
+            tris.append(rt.make_triangle(tuple(t.a), tuple(t.b), tuple(t.c), int(rng.integers(0, len(mats)))))
+            continue
+        a, b, cc = c, c + e1, c + e2
+        tris.append(rt.make_triangle(tuple(map(float, a)), tuple(map(float, b)), tuple(map(float, cc)),
+                                     int(rng.integers(0, len(mats)))))
+    for k in range(n_sph):
+        c = rng.uniform(-span, span, 3)
+        spheres.append(rt.Sphere((f32 * 3)(*map(float, c)), float(rng.uniform(0.05, 0.4) * span),
+                                 int(rng.integers(0, len(mats))), k))
+    for k, t in enumerate(tris):
+        t.object_id = n_sph + k
+    order = list(range(n_sph)) + [rt.REF_TRIANGLE | k for k in range(len(tris))]
+    rng.shuffle(order)
+    lights = []
+    for k in range(int(rng.integers(1, 4))):
+        p = rng.uniform(-2 * span, 2 * span, 3)
+        lights.append(rt.Light((f32 * 3)(*map(float, p)), (f32 * 3)(0.1 * span, 0, 0), (f32 * 3)(0, 0, 0.1 * span),
+                               (f32 * 3)(0.6, 0.6, 0.6)))
+    sc = rt.Scene.create(spheres, tris, [int(x) for x in order], mats, lights, bvh="sah")
+    inside = rng.integers(0, 2) == 0
+    eye = rng.uniform(-0.5 * span, 0.5 * span, 3) if inside else rng.uniform(1.5 * span, 2.5 * span, 3)
+    cfg = rt.Config(image_width=96, image_height=72, view_width=8, view_height=6, view_distance=int(rng.integers(3, 8)),
+                    reflection_depth=int(rng.integers(1, 6)), anti_aliasing=4,
+                    eye=tuple(map(float, eye)), look_at=tuple(map(float, rng.uniform(-0.3 * span, 0.3 * span, 3))),
+                    lens=float(rng.choice([0.0, 0.0, 0.05 * span])))
+    return rt.config_to_world(cfg, sc)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_soups_match_oracle(rt, oracle, renderer, seed):
+    """Fuzz: scenes nobody designed (`_random_soup`), both ray policies.  Hit ids and ray counts
+    identical, the 8-bit frame within 1 -- the same bar as the designed scenes."""
+    w = _random_soup(rt, 1000 + seed)
+    for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT), (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
+        (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 40 + seed, gflags, oflags)
+        assert int((g_ids != o_ids).sum()) == 0
+        assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+               (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+        check_image(rt, g_rgb, o_rgb)
