@@ -45,6 +45,7 @@ rtd = importlib.import_module("ray-tracer_amd.distributed")
 
 PEAK_VALU_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBPS = 8000.0     # HBM3E spec
+PEAK_VALU_ISSUE = 1228.8   # G wave64 instructions/s: 1024 SIMDs x 2.4 GHz / 2 cycles (the issue rate behind PEAK_VALU_TFLOPS)
 BYTES_PER_RAY = 128        # 56-B ray record written+read once + 8-B hit record x2
 SEED = 0x5EED1234
 
@@ -97,7 +98,7 @@ def pmc_traffic(workload: str):
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_pmc.txt")))
     if not found:
-        return None, None
+        return None, None, {}
     path = found[-1]   # the newest round's pass
     vals = {}
     for line in open(path):
@@ -105,8 +106,8 @@ def pmc_traffic(workload: str):
         if len(f) >= 3 and f[-1].startswith("avg="):
             vals[f[0]] = float(f[-1][4:])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None
-    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+        return None, None, vals
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), vals
 
 
 def cpu_baseline(world, grids, seconds_target: float = 25.0):
@@ -326,7 +327,7 @@ def main() -> None:
         #  average for the timed kernel)
         r.render_async(df.frames[0].data_ptr(), 0, args.flags | rt.FLAG_TRACE_ZERO_WEIGHT | rt.FLAG_COUNT_TESTS, stream)
         out["config"]["rays_per_frame_reference_accounting"] = int(r.collect(stream).rays_total)
-        traffic, traffic_src = pmc_traffic(args.workload)
+        traffic, traffic_src, pmc = pmc_traffic(args.workload)
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(tf, 3), "peak": PEAK_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
@@ -350,6 +351,23 @@ def main() -> None:
                     "fp32 VALU issue (PMC: profiles/), not HBM; hbm.achieved is counter traffic over "
                     "kernel time; model_* price the ray-queue streaming model of SURVEY 8(d)",
         }
+        if "SQ_INSTS_VALU" in pmc:
+            # The bound that binds ("What the measurements say"): VALU ISSUE.  Wave64
+            # instructions per launch from the committed counter pass over this run's kernel time,
+            # against 1024 SIMDs x 2.4 GHz / 2 cycles -- the rate of full-rate two-operand fp32, which
+            # is what the 157.3 TFLOP/s peak assumes.  Three-operand, compare/select and 64-bit
+            # encodings take ~4 cycles (tools/micro/mix_rate.hip): this kernel's mix can issue at
+            # ~3.1 cycles per instruction at best, i.e. frac ~0.65 is its ceiling.
+            wi = pmc["SQ_INSTS_VALU"]
+            rate = wi / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["valu_issue"] = {
+                "achieved": round(rate, 1), "peak": PEAK_VALU_ISSUE, "unit": "G wave64 instructions/s",
+                "frac": round(rate / PEAK_VALU_ISSUE, 4),
+                "wave_instructions_per_launch": wi,
+                "cycles_per_instruction_per_simd": round(1024 * 2.4e9 * kernel_ms * 1e-3 / wi, 2),
+                "lanes_active": round(pmc["SQ_THREAD_CYCLES_VALU"] / (wi * 64), 3)
+                if "SQ_THREAD_CYCLES_VALU" in pmc else None,
+                "from_committed_pmc_pass": traffic_src}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, grids)
     if rank == 0:
