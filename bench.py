@@ -297,7 +297,16 @@ def main() -> None:
         same = all(torch.equal(ref, f) for f in df.frames)
         out["config"]["collective_path_frame_identical"] = bool(same)
         if not same:
-            raise SystemExit("gathered + assembled frame differs from the directly rendered one")
+            detail = []
+            for i, f in enumerate(df.frames):
+                bad = torch.nonzero(ref != f).flatten()
+                if bad.numel():
+                    lower = int((f[bad] < ref[bad]).sum())
+                    zero = int((f[bad] == 0).sum())
+                    detail.append(f"slot {i}: {bad.numel()} of {ref.numel()} floats differ ({lower} lower than the direct "
+                                  f"frame, {zero} of them zero), first at {int(bad[0])}, last at {int(bad[-1])}")
+            raise SystemExit("gathered + assembled frame differs from the directly rendered one (mode "
+                             f"{df.mode}, {df.k} frames submitted): " + "; ".join(detail))
     if world_size == 1 and not args.force_collective and not args.rehearse_share:
         # Roofline of the dominant kernel.  Its launch duration is measured with HIP events
         # recorded by the library on the launch stream right around render_kernel

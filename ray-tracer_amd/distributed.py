@@ -106,6 +106,7 @@ class DistributedFrame:
         # force_collective: run the gather/assemble path even with one rank (self-test on a
         # one-GPU box of exactly the code the 8-GPU job runs)
         self.collective = nranks > 1 or force_collective
+        self.poison = force_collective
         if not self.collective:
             return
         self.mine = [torch.zeros(self.stride, dtype=torch.float32, device=device)
@@ -115,6 +116,7 @@ class DistributedFrame:
         self.works = [None] * self.depth
         self.asm_stream = torch.cuda.Stream(device=device)
         self.asm_done = [None] * self.depth
+        self.own_copied = [torch.cuda.Event() for _ in range(self.depth)]
 
     def _choose_mode(self, share_gpu: str):
         """(frames in flight, grid divisor) -- local timing only, no collective."""
@@ -193,12 +195,26 @@ class DistributedFrame:
                 self.works[slot].wait()          # mine[slot] is free once its gather is done
             if self.asm_done[slot] is not None:
                 rs.wait_event(self.asm_done[slot])  # gathered[slot]/frames[slot] free once assembled
+            if self.poison:
+                # self-test: whatever is read before it was written this frame shows as NaN (a still
+                # frame rendered twice would otherwise hide a premature read behind the old copy)
+                self.mine[slot].fill_(float("nan"))
+                if self.is_root:
+                    self.gathered[slot].fill_(float("nan"))
+                    self.frames[slot].fill_(float("nan"))
             r.render_tiles_async(self.mine[slot].data_ptr(), flags, rs.cuda_stream)
             # the collective's stream picks up after the kernel just enqueued on rs
             self.works[slot] = gather_tiles(self.mine[slot], self.gathered[slot], 0, async_op=True)
+            if self.is_root:
+                # The root's OWN tiles reach gathered[slot] by a device copy that the process group
+                # enqueues on the stream that is current at the call (rs), not on the collective's:
+                # waiting for the collective's work does not cover it.  (Seen with one rank, 6 frames
+                # in flight, first use of a slot: 2 % of the frame still zero when assembled.)
+                self.own_copied[slot].record(rs)
         if self.is_root:
             with torch.cuda.stream(self.asm_stream):
                 self.works[slot].wait()
+                self.asm_stream.wait_event(self.own_copied[slot])
                 r.assemble_async(self.gathered[slot].data_ptr(), self.nranks, self.stride,
                                  self.frames[slot].data_ptr(), self.asm_stream.cuda_stream)
                 ev = torch.cuda.Event()
