@@ -93,6 +93,10 @@ struct rt_ctx {
   int batches = 0;                 // RT_BATCHES
   int refr_cap = 0, refl_cap = 0;  // RT_REFR_CAP / RT_REFL_CAP (0 = default)
   int rearm_min = 0;               // RT_REARM_MIN (0 = default)
+  // probe_kernel's sampling density (scheduling only): one ray per multi-pixel packet (two cost c2 1-2 %
+  // of the frame and bought no better order), one ray per FOUR single-pixel packets (64 spp: the
+  // DOF frame 4.80 -> 4.71 ms; 8 and 16 are no better).  RT_PROBE_TWO, RT_PROBE_GROUP override.
+  int probe_two = 0, probe_group = 4;
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
 };
 
@@ -796,6 +800,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.refr_cap = c->refr_cap > 0 ? c->refr_cap : 1;  // measured: 1/1 never worse on the small scenes, c3 (mesh) 28.8 -> 21.7 ms
   p.refl_cap = c->refl_cap > 0 ? c->refl_cap : 1;
   p.rearm_min = c->rearm_min > 0 ? std::min(c->rearm_min, 64) : 12;
+  p.probe_two = c->probe_two;
+  p.probe_group = std::max(1, std::min(c->probe_group, 16));
   p.batch_div = std::max(1, 2 * cfg.grid * wpb / PACKET_SHARDS);  // 2 x waves per shard
   p.packets_per_shard = (p.n_packets + PACKET_SHARDS - 1) / PACKET_SHARDS;
   p.probe_span = std::max(256, ((p.n_packets + 1023) / 1024 + 255) / 256 * 256);  // <= 1024 blocks
@@ -899,6 +905,8 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_REFR_CAP")) c->refr_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REFL_CAP")) c->refl_cap = std::atoi(e);
   if (const char *e = std::getenv("RT_REARM_MIN")) c->rearm_min = std::atoi(e);
+  if (const char *e = std::getenv("RT_PROBE_TWO")) c->probe_two = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RT_PROBE_GROUP")) c->probe_group = std::atoi(e);
   if (const char *e = std::getenv("RT_FIVE_WAVES")) c->five_waves_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_DEBUG_CLEAR_BAND")) c->clear_band = (float)std::atof(e);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&

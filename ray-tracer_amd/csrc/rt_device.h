@@ -128,6 +128,7 @@ struct RenderParams {
   FastDiv fd_groups_per_tile, fd_tiles_x, fd_spp, fd_tile_w, fd_n_grids;  // the hot loop's divisors
   int point_words;                       // LDS words per wave for the step's shaded points (point_words_for; 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
+  int probe_two, probe_group;            // probe_kernel: two rays per multi-pixel packet (else one); single-pixel packets classified per ray
 };
 
 struct LaunchCfg {

@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
 
 // ---- packet cost classes (scheduling only; never affects a pixel value) ---------------
 // One packet costs between ~2 rays per sample (diffuse floor) and ~100 (glass: a binary
-// ray tree of depth wMaxDepth).  probe_kernel shoots 4 rays per packet and classifies
+// ray tree of depth wMaxDepth).  probe_kernel shoots one ray per packet (or per four single-pixel packets) and classifies
 // it by the material of the first hit; order_kernel then counting-sorts the packets,
 // most expensive class first (stable, no atomics).
 //   class 3 refractive | 2 reflective (non-zero reflection weight) | 1 other hit | 0 miss
@@ -1555,15 +1555,21 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
   const int span = P.probe_span;  // packets per block (multiple of 256)
   const int first = blockIdx.x * span;
   Counters cn = {0, 0, 0};
-  // probe rays per packet: two (through opposite quadrants of two of its pixels) when the packet
-  // has several pixels, one through the centre when it is a single pixel (64 spp and more)
-  const int two = P.px_per_packet >= 2 ? 1 : 0;
-  for (int base = first; base < first + span; base += 256 >> two) {  // uniform trip count per block
-    const int packet = base + (int)(threadIdx.x >> two), sub = two ? (int)(threadIdx.x & 1) * 3 : 0;
+  // probe rays: one through the centre of the packet's middle pixel (P.probe_two: two, through
+  // opposite quadrants of two of its pixels); single-pixel packets (64 spp and more) are classified
+  // P.probe_group at a time by one ray
+  const int two = (P.px_per_packet >= 2 && P.probe_two) ? 1 : 0;
+  // single-pixel packets: one ray may stand for `grp` consecutive packets (pixels of one tile row)
+  const int grp = P.px_per_packet >= 2 ? 1 : P.probe_group;
+  for (int base = first; base < first + span; base += (256 >> two) * grp) {  // uniform trip count per block
+    const int packet = base + (int)(threadIdx.x >> two) * grp;
+    const int sub = two ? (int)(threadIdx.x & 1) * 3 : (P.px_per_packet >= 2 ? P.px_per_packet / 2 : 0);
     bool inside = false;
     int px = 0, py = 0;
     const bool valid = packet < P.n_packets && packet < first + span;
-    if (valid) decode_packet(P, packet, sub, px, py, inside);
+    // (the ray goes through the group's second packet when there is one)
+    const int shot = (grp > 1 && packet + 1 < P.n_packets && packet + 1 < first + span) ? packet + 1 : packet;
+    if (valid) decode_packet(P, shot, sub, px, py, inside);
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (inside) {
       float fi = (float)px + (two ? 0.25f + 0.5f * (float)(sub & 1) : 0.5f);
@@ -1582,9 +1588,14 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
       cls = (M[8] != 0) ? 3 : (mirror ? 2 : 1);
     }
     if (two) cls = max(cls, __shfl_xor(cls, 1));
-    if (valid && sub == 0) {
-      P.pclass[packet] = (unsigned char)cls;
-      atomicAdd(&hist[cls], 1u);
+    if (valid && (!two || (threadIdx.x & 1) == 0)) {
+      unsigned n_in = 0;
+      for (int j = 0; j < grp; ++j)
+        if (packet + j < P.n_packets && packet + j < first + span) {
+          P.pclass[packet + j] = (unsigned char)cls;
+          ++n_in;
+        }
+      atomicAdd(&hist[cls], n_in);
     }
   }
   __syncthreads();
