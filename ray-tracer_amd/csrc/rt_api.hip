@@ -109,7 +109,7 @@ struct rt_ctx {
 constexpr size_t ST_MAX_PIXELS = 1u << 18;   // local pixels incl. tile padding (e.g. 640x360, 512x512)
 constexpr int ST_MAX_WAVES = 512;            // persistent waves of the launch (the normal path uses up to 5120)
 constexpr int ST_MAX_DEPTH = 6;              // wMaxDepth (every shipped config uses 6)
-constexpr size_t ST_STATS_BYTES = (16 + 4 * 16384 + 32) * sizeof(unsigned long long);
+constexpr size_t ST_STATS_BYTES = STATS_WORDS * sizeof(unsigned long long);
 constexpr size_t ST_COUNTER_BYTES = PACKET_SHARDS * 32 * sizeof(unsigned);
 constexpr size_t ST_HIST_BYTES = (1024 * 4 + 64) * sizeof(unsigned);
 constexpr size_t ST_ORDER_ENTRIES = ST_MAX_PIXELS;  // one entry per packet, or per pixel of a refractive packet
@@ -438,6 +438,46 @@ struct WideBuild {
       std::memcpy(w + 24 + i, &refs[i], 4);
     }
     return me;
+  }
+
+  // Renumber the records so that the first `top` of them are the top of the tree in BREADTH-first
+  // order (the kernel keeps a prefix of the table on chip: "record index < n" must mean "one of the n
+  // records nearest the root"); the others keep their depth-first order (a subtree's records stay
+  // together in memory).  Record 0 stays the root.
+  void breadth_first_top(int top) {
+    const int n = (int)(wide.size() / 32);
+    if (n <= 2) return;
+    std::vector<int> order;   // new index -> old index
+    std::vector<char> taken((size_t)n, 0);
+    order.reserve((size_t)n);
+    order.push_back(0);
+    taken[0] = 1;
+    for (size_t head = 0; head < order.size() && (int)order.size() < top; ++head) {
+      const float *w = &wide[(size_t)order[head] * 32];
+      for (int i = 0; i < 4 && (int)order.size() < top; ++i) {
+        const int ref = get_i(w + 24 + i);
+        if (ref >= 0 && !taken[ref]) { taken[ref] = 1; order.push_back(ref); }
+      }
+    }
+    for (int i = 0; i < n; ++i)
+      if (!taken[i]) order.push_back(i);
+    std::vector<int> new_of((size_t)n);
+    for (int i = 0; i < n; ++i) new_of[order[i]] = i;
+    std::vector<float> w2(wide.size());
+    std::vector<int> s2(src.size());
+    for (int i = 0; i < n; ++i) {
+      std::memcpy(&w2[(size_t)i * 32], &wide[(size_t)order[i] * 32], 128);
+      for (int k = 0; k < 4; ++k) {
+        s2[(size_t)i * 4 + k] = src[(size_t)order[i] * 4 + k];
+        int ref = get_i(&w2[(size_t)i * 32 + 24 + k]);
+        if (ref >= 0) {
+          ref = new_of[ref];
+          std::memcpy(&w2[(size_t)i * 32 + 24 + k], &ref, 4);
+        }
+      }
+    }
+    wide.swap(w2);
+    src.swap(s2);
   }
 };
 
@@ -817,7 +857,7 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (p.n_packets == 0) {
     HIP_TRY(c, hipMemsetAsync(m.tile_counter, 0, PACKET_SHARDS * 32 * sizeof(unsigned), s));
     HIP_TRY(c, hipMemsetAsync(m.stats, 0, 16 * sizeof(unsigned long long), s));
-    HIP_TRY(c, hipMemsetAsync(m.stats + 16 + 4 * 16384, 0, 32 * sizeof(unsigned long long), s));
+    HIP_TRY(c, hipMemsetAsync(m.stats + STATS_DIAG_BASE, 0, STATS_DIAG_WORDS * sizeof(unsigned long long), s));
   }
   if (!m.acc_known_clean && m.acc_pixels)
     HIP_TRY(c, hipMemsetAsync(m.acc, 0, m.acc_pixels * 3 * sizeof(long long), s));
@@ -914,7 +954,7 @@ int rt_init(int device, rt_ctx **out) {
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
             hipEventCreate(&c->evt0) == hipSuccess && hipEventCreate(&c->evt1) == hipSuccess &&
             hipMalloc((void **)&c->d_tile_counter, PACKET_SHARDS * 32 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void **)&c->d_stats, (16 + 4 * 16384 + 32) * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void **)&c->d_stats, STATS_WORDS * sizeof(unsigned long long)) == hipSuccess;
   if (!ok) {
     rt_shutdown(c);
     return RT_ERR_DEVICE;
@@ -988,8 +1028,10 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     wb.cap = std::max(std::max(3, depth_max - 1), rp.max_depth);
   }
   wb.height.assign(rp.nodes.size() / 16, -1);
-  if (sc->n_nodes > 0) wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
-  else {
+  if (sc->n_nodes > 0) {
+    wb.build(0, 0);   // binary record 0 is the pseudo root: its only child is the real root
+    wb.breadth_first_top(WIDE_BFS_TOP);
+  } else {
     wb.wide.assign(32, 0.0f);
     for (int i = 0; i < 24; ++i) wb.wide[i] = ((i >> 2) & 1) ? -WideBuild::ABSENT_PLANE : WideBuild::ABSENT_PLANE;
     std::fill(wb.wide.begin() + 24, wb.wide.begin() + 28, Repack::as_f(REF_NONE));
@@ -1290,7 +1332,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   if (!c || !out || max_waves < 1) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
-  int n = std::min<int>(max_waves, 16384 + 8);  // the last 8 rows: phase sums of a profiling build
+  int n = std::min<int>(max_waves, STATS_MAX_WAVES + STATS_DIAG_WORDS / 4);  // the last rows: sums of a profiling build
   HIP_TRY(c, hipMemcpy(out, (c->last_stats ? c->last_stats : c->d_stats) + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }

@@ -50,6 +50,7 @@ constexpr int PRIM_F4 = 4;
 // leaf_box_clear; leaf boxes: RenderParams::leafbox).  The closest hit is order-independent under
 // the total order of the tie rule.  Record 0 is the root.
 constexpr int WNODE_F4 = 8;
+constexpr int WIDE_BFS_TOP = 1024;  // the first this-many wide records are the top of the tree in breadth-first order (rt_api.hip)
 constexpr int LDS_WNODE_F4 = 9;  // LDS stride of a wide record: 36 dwords, walks all sixteen 4-bank groups
 constexpr int LDS_REC_F4 = 5;  // stride of a node/primitive record in the LDS scene copy (80 B, see rt_kernels.inl)
 
@@ -72,6 +73,14 @@ constexpr int MAX_DEPTH = 30;   // wMaxDepth limit (levels kept in an LDS counte
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int HOT_WORDS = 64;    // LDS words per block for RenderParams::hot and the first light
 constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)
+// Statistics block (unsigned long long words): [0..15] frame totals (rt_stats order), [16 .. 16 + 4 * 16384)
+// four words per wave (rt_wave_diag), then STATS_DIAG_WORDS of a profiling build's sums: [0..11] phase
+// cycles, [12] steps, [13] active lanes, [16..23] traversal iterations / lane shares, [32..71] deepest
+// stack per closest-hit traversal, [72..111] per shadow ray of the pool, [112..119] wide-node visits
+// with record index < 64 << k (k = 0..6) and all
+constexpr int STATS_WAVE_BASE = 16, STATS_MAX_WAVES = 16384;
+constexpr int STATS_DIAG_BASE = STATS_WAVE_BASE + 4 * STATS_MAX_WAVES, STATS_DIAG_WORDS = 160;
+constexpr int STATS_WORDS = STATS_DIAG_BASE + STATS_DIAG_WORDS;
 
 struct RenderParams {
   const float4 *nodes;

@@ -61,12 +61,23 @@ struct Counters {
   // (summed over the lanes: lane-iterations and 2^20 x wave-iterations).  [0] node steps,
   // [1] leaf steps of closest-hit traversals, [2], [3] the same for shadow traversals
   unsigned long long iters[4], lanes[4];
+  // deepest stack of the traversal in progress (entries), and this lane's wide-node visits with a
+  // record index below 64 << k (k = 0..6) / in all
+  unsigned spmax;
+  unsigned topk[8];
 #endif
 };
 #ifdef RT_PROFILE_PHASES
 #define DIV_COUNT(cn, i) do { (cn).iters[i] += 1; (cn).lanes[i] += (1u << 20) / (unsigned)__popcll(__ballot(true)); } while (0)
+#define SP_COUNT(cn, sp) do { if ((unsigned)(sp) > (cn).spmax) (cn).spmax = (unsigned)(sp); } while (0)
+#define TOPK_COUNT(cn, idx) do { for (int k_ = 0; k_ < 7; ++k_) (cn).topk[k_] += (idx) < (64 << k_); (cn).topk[7] += 1; } while (0)
+// one traversal is over: its deepest stack goes into histogram `which` (0 closest hit, 1 shadow-ray pool)
+#define SP_FLUSH(P, cn, which) do { atomicAdd(&(P).stats[STATS_DIAG_BASE + 32 + 40 * (which) + ((cn).spmax < 39u ? (cn).spmax : 39u)], 1ull); (cn).spmax = 0; } while (0)
 #else
 #define DIV_COUNT(cn, i)
+#define SP_COUNT(cn, sp)
+#define TOPK_COUNT(cn, idx)
+#define SP_FLUSH(P, cn, which)
 #endif
 
 // ---- exact division by a per-ray constant ---------------------------------------------
@@ -398,6 +409,7 @@ template <bool ANY, bool COUNT, bool LDS>
 DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
                     const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
   const float4 *np = wnode_rec<LDS>(P, sc, cur);
+  TOPK_COUNT(cn, cur);
   const float4 rf = np[6];
   int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
   if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
@@ -455,6 +467,7 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
     sl += p2 ? 64 : 0;
     sl[0] = (unsigned)r1;
     sp += (int)p1 + (int)p2 + (int)p3;
+    SP_COUNT(cn, sp);
     if (h0 || h1 || h2 || h3) {
       cur = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
     } else if (sp > 0) {
@@ -484,6 +497,7 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
   sl += (n >= 3) ? 64 : 0;
   sl[0] = (unsigned)r1;
   sp += (n >= 2 ? n - 1 : 0);
+  SP_COUNT(cn, sp);
   if (n >= 1) {
     cur = r0;
   } else if (sp > 0) {
@@ -638,6 +652,7 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       cur = 0;
     }
   }
+  if (active) SP_FLUSH(P, cn, ANY ? 1 : 0);
 }
 
 // The sampled point on light li and the shadow ray towards it (getDirectColor :96-100).
@@ -711,6 +726,8 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   int cl = hi - lo;                // current light (bit index); its unserved points in `rm`
   unsigned long long rm = 0ull;    // both wave-uniform
   int cur = STOP, sp = 0, owner = 0, bit = 0;
+  bool armed = false;  // (profiling build: this lane has taken a ray of the pool)
+  (void)armed;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
   float tlimit = 0.0f;
   RayDiv rd;
@@ -737,6 +754,8 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       __threadfence_block();
       const int rank = __popcll(idle & lt_mask);
       if (cur == STOP && rank < n_take) {
+        if (armed) SP_FLUSH(P, cn, 1);
+        armed = true;
         owner = (int)handout[rank];
         bit = cl;
         o = mk(__uint_as_float(pts[0 * 64 + owner]), __uint_as_float(pts[1 * 64 + owner]),
@@ -772,6 +791,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       }
     }
   }
+  if (armed) SP_FLUSH(P, cn, 1);
   __threadfence_block();
   return hit ? occl[lane] : 0u;
 }
@@ -1489,9 +1509,10 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   // ---- statistics --------------------------------------------------------------------
 #ifdef RT_PROFILE_PHASES
   for (int i = 0; i < 4; ++i) {
-    atomicAdd(&P.stats[65536 + 16 + 16 + i], cn.iters[i]);
-    atomicAdd(&P.stats[65536 + 16 + 20 + i], cn.lanes[i]);
+    atomicAdd(&P.stats[STATS_DIAG_BASE + 16 + i], cn.iters[i]);
+    atomicAdd(&P.stats[STATS_DIAG_BASE + 20 + i], cn.lanes[i]);
   }
+  for (int i = 0; i < 8; ++i) atomicAdd(&P.stats[STATS_DIAG_BASE + 112 + i], (unsigned long long)cn.topk[i]);
 #endif
   if (lane == 0) {
     const unsigned long long wave_t0 = P.stats[16 + gwave * 4];
@@ -1512,9 +1533,9 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     P.stats[18 + gwave * 4] = ((unsigned long long)n_steps << 40) | (wave_t0 & 0xFFFFFFFFFFull);
     P.stats[19 + gwave * 4] = t_dry - wave_t0;  // when the packet supply ran dry for this wave
 #ifdef RT_PROFILE_PHASES
-    for (int i = 0; i < 12; ++i) atomicAdd(&P.stats[65536 + 16 + i], ph_acc[i]);
-    atomicAdd(&P.stats[65536 + 16 + 12], ph_steps);
-    atomicAdd(&P.stats[65536 + 16 + 13], ph_lanes);
+    for (int i = 0; i < 12; ++i) atomicAdd(&P.stats[STATS_DIAG_BASE + i], ph_acc[i]);
+    atomicAdd(&P.stats[STATS_DIAG_BASE + 12], ph_steps);
+    atomicAdd(&P.stats[STATS_DIAG_BASE + 13], ph_lanes);
 
 #endif
   }
@@ -1615,7 +1636,7 @@ __global__ __launch_bounds__(256) void order_kernel(const RenderParams P) {
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < PACKET_SHARDS * 32; i += 256) P.tile_counter[i] = 0u;
     if (threadIdx.x < 16) P.stats[threadIdx.x] = 0ull;
-    if (threadIdx.x < 32) P.stats[16 + 4 * 16384 + threadIdx.x] = 0ull;
+    if (threadIdx.x < STATS_DIAG_WORDS) P.stats[STATS_DIAG_BASE + threadIdx.x] = 0ull;
   }
   // totals of every class and the counts of the blocks before this one
   unsigned tot[PROBE_CLASSES] = {0, 0, 0, 0}, before[PROBE_CLASSES] = {0, 0, 0, 0};

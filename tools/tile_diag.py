@@ -42,7 +42,7 @@ for wl in sys.argv[1:] or ["c2"]:
     slow = np.argsort(end)[-6:]
     print('   slowest waves (rays, steps, dry us, end us):', [(int(wd[i,1]), int(steps[i]), int(dry[i]), int(end[i])) for i in slow],
           ' median wave (rays, steps):', int(np.median(wd[:,1])), int(np.median(steps)))
-    ph = r.wave_diag(16384 + 8)[16384:].reshape(-1).astype(float)
+    ph = r.wave_diag(16384 + 40)[16384:].reshape(-1).astype(float)
     if ph[:6].sum() > 0:
         names = ["pop/other", "closest traversal", "shade (direct)", "shadow traversal", "accumulate", "emit bounces",
                  "level select", "packet decode", "samples+getRay", "fetch next packet", "-", "-"]
@@ -53,5 +53,16 @@ for wl in sys.argv[1:] or ["c2"]:
         for nm, i in (("closest node", 0), ("closest leaf", 1), ("shadow node", 2), ("shadow leaf", 3)):
             lane_it, wave_it = ph[16 + i], ph[20 + i] / 2.0**20
             print(f"   {nm} iterations: {wave_it/max(1,ph[12]):.1f} per scheduling step, {lane_it/max(1,wave_it):.1f} lanes in each")
+        for nm, off in (("closest-hit traversals", 32), ("shadow rays of the pool / single-light shadow traversals", 72)):
+            h = ph[off:off + 40]
+            if h.sum() > 0:
+                c = np.cumsum(h) / h.sum()
+                print(f"   deepest stack per traversal, {nm} ({int(h.sum())}): " +
+                      " ".join(f"<={d}:{100*c[d]:.3f}%" for d in (2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28) if d < 40) +
+                      f"  max {int(np.nonzero(h)[0].max())}")
+        tk = ph[112:120]
+        if tk[7] > 0:
+            print("   wide-node visits with record index below: " + " ".join(f"{64 << k}:{100*tk[k]/tk[7]:.1f}%" for k in range(7)) +
+                  f"  (of {int(tk[7])} lane visits)")
         print(f"   steps {int(ph[12])}  avg active lanes/step {ph[13]/max(1,ph[12]):.1f}  cycles/step/wave {tot/max(1,ph[12]):.0f}")
     r.close()
