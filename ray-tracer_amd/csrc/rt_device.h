@@ -138,6 +138,11 @@ struct RenderParams {
   int point_words;                       // LDS words per wave for the step's shaded points (point_words_for; 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
   int probe_two, probe_group;            // probe_kernel: two rays per multi-pixel packet (else one); single-pixel packets classified per ray
+  // TOP builds (scene in memory, its top records in LDS, short stacks that overflow to memory):
+  int stack_cap, lds_top;                // LDS stack entries per lane (stack_depth = stack_cap + 1); wide records kept in LDS
+  unsigned *spill;                       // per wave: [spill rows][64] stack entries that did not fit
+  unsigned long long spill_stride;       // words per wave
+  int probe_stack_depth, pad1;           // probe_kernel's own (full-depth) stacks
 };
 
 struct LaunchCfg {
@@ -148,6 +153,7 @@ struct LaunchCfg {
   bool lds_scene;           // render from the block's LDS copy of the scene
   bool five_waves;          // the 96-VGPR build: LDS scene of <= 32 KB per block, one light, pruned, uncounted
   bool mlight;              // more than one light: the build with the shadow-ray pool (pruned, uncounted launches)
+  bool top;                 // scene in memory with its top wide records in LDS and short spilling stacks (block = 512 or 1024)
   size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
   size_t probe_lds_bytes;   // probe_kernel: the traversal stacks of its own four waves
 };

@@ -52,7 +52,11 @@ for wl in sys.argv[1:] or ["c2"]:
         print("   phases (share of summed wave cycles): " + "  ".join(f"{n} {100*v/tot:.1f}%" for n, v in zip(names, ph[:12]) if v))
         for nm, i in (("closest node", 0), ("closest leaf", 1), ("shadow node", 2), ("shadow leaf", 3)):
             lane_it, wave_it = ph[16 + i], ph[20 + i] / 2.0**20
-            print(f"   {nm} iterations: {wave_it/max(1,ph[12]):.1f} per scheduling step, {lane_it/max(1,wave_it):.1f} lanes in each")
+            print(f"   {nm} iterations: {wave_it/max(1,ph[12]):.1f} per scheduling step, {lane_it/max(1,wave_it):.1f} lanes in each, "
+                  f"{ph[24 + i]/max(1,wave_it):.0f} cycles of wave time each ({100*ph[24 + i]/tot:.1f}% of all wave cycles)")
+        if ph[29] > 0:
+            print(f"   shadow-ray pool re-arms: {ph[29]/max(1,ph[12]):.1f} per scheduling step, {ph[30]/ph[29]:.1f} rays handed out in each, "
+                  f"{ph[28]/ph[29]:.0f} cycles of wave time each ({100*ph[28]/tot:.1f}% of all wave cycles)")
         for nm, off in (("closest-hit traversals", 32), ("shadow rays of the pool / single-light shadow traversals", 72)):
             h = ph[off:off + 40]
             if h.sum() > 0:
