@@ -98,15 +98,6 @@ struct rt_ctx {
   // DOF frame 4.80 -> 4.71 ms; 8 and 16 are no better).  RT_PROBE_TWO, RT_PROBE_GROUP override.
   int probe_two = 0, probe_group = 4;
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
-  // Scenes too big for LDS: the top wide records on chip beside short stacks that overflow to memory
-  // (render_kernel<..., TOP>).  RT_TOP: 0 = never (full-depth LDS stacks, 4-wave blocks), 8 / 16 = waves per
-  // block (default 16: one copy of the tree's top per CU); RT_STACK_CAP: LDS stack entries per lane;
-  // RT_LDS_TOP: most records kept on chip.
-  bool big_scene = false;   // decided at upload: primitives + nodes cannot fit in a block's LDS
-  int top_mode = 16, stack_cap = 12, lds_top_max = WIDE_BFS_TOP;
-  unsigned *d_spill = nullptr;
-  size_t spill_words = 0;
-  unsigned long long spill_stride = 0;
 };
 
 // ---- the library's static work memory (rt_render_static_async) --------------------------
@@ -167,8 +158,6 @@ struct WorkMem {
   unsigned *block_hist = nullptr;
   int *order = nullptr;
   size_t order_cap = 0;
-  unsigned *spill = nullptr;     // stack overflow area of the TOP builds (null: full-depth LDS stacks)
-  unsigned long long spill_stride = 0;
   bool acc_known_clean = false;  // every pixel sum is zero (left so by the previous resolve_kernel)
   int max_waves = 1 << 30;       // cap of the launch's persistent waves
 };
@@ -658,18 +647,6 @@ int prepare(rt_ctx *c) {
     c->scratch_floats = need;
   }
   c->scratch_waves = waves;
-  if (c->big_scene && c->top_mode != 0) {
-    // per wave one 64-lane row per stack entry a traversal can hold beyond the LDS part (plus slack)
-    c->spill_stride = (unsigned long long)(c->wide_stack + 4) * 64;
-    const size_t need_spill = (size_t)waves * c->spill_stride;
-    if (need_spill > c->spill_words) {
-      if (c->d_spill) (void)hipFree(c->d_spill);
-      c->d_spill = nullptr;
-      c->spill_words = 0;
-      HIP_TRY(c, hipMalloc((void **)&c->d_spill, need_spill * sizeof(unsigned)));
-      c->spill_words = need_spill;
-    }
-  }
   {
     size_t n_entries = order_entries(c);
     if (n_entries > c->order_cap || !c->d_order) {
@@ -702,10 +679,6 @@ WorkMem own_work_memory(const rt_ctx *c) {
   m.order = c->d_order;
   m.order_cap = c->order_cap;
   m.acc_known_clean = c->acc_clean;
-  if (c->big_scene && c->top_mode != 0 && c->d_spill) {
-    m.spill = c->d_spill;
-    m.spill_stride = c->spill_stride;
-  }
   return m;
 }
 
@@ -833,24 +806,6 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
     cfg.lds_scene = true;
   }
   if (!cfg.lds_scene) cfg.lds_scene_bytes = 0;
-  p.probe_stack_depth = stack_depth;
-  cfg.top = prune && !cfg.count && !cfg.lds_scene && m.spill != nullptr;
-  if (cfg.top) {
-    // Scene in memory: one 16-wave block per CU (or two 8-wave blocks) with short spilling stacks;
-    // what the stacks leave of the CU's 160 KB holds the top of the tree.
-    wpb = c->top_mode == 8 ? 8 : (c->top_mode == 4 || c->top_mode == 5) ? 4 : 16;
-    const int blocks_per_cu = c->top_mode == 5 ? 5 : 16 / wpb;
-    cfg.block = 64 * wpb;
-    p.stack_cap = std::max(8, std::min(c->stack_cap, 60)) & ~1;
-    p.stack_depth = p.stack_cap + 1;
-    const size_t waves_bytes = lds_bytes_for(p.stack_depth, p.point_words, wpb);
-    const size_t budget = (size_t)160 * 1024 / blocks_per_cu - HOT_WORDS * 4 - waves_bytes;
-    p.lds_top = (int)std::min<size_t>(std::min(c->n_wnode_recs, std::min(c->lds_top_max, WIDE_BFS_TOP)), budget / (LDS_WNODE_F4 * 16));
-    cfg.lds_scene_bytes = (size_t)p.lds_top * LDS_WNODE_F4 * 16;
-    cfg.lds_bytes = waves_bytes;
-    p.spill = m.spill;
-    p.spill_stride = m.spill_stride;
-  }
   cfg.lds_bytes += cfg.lds_scene_bytes + HOT_WORDS * 4;   // + the block's copy of RenderParams::hot
   // The 96-VGPR build (five waves per SIMD): small single-light LDS scenes, and only when a wave
   // has many packets to work through -- on a small share of a frame the extra waves only add
@@ -859,9 +814,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
                    cfg.lds_bytes <= 32 * 1024 &&  // five 4-wave blocks share a CU's 160 KB
                    (c->five_waves_mode > 0 ||
                     (c->five_waves_mode < 0 && (long long)p.n_packets >= 64ll * c->n_cus * 20));
-  if (cfg.top && c->top_mode == 5) cfg.five_waves = true;
   const bool fma = (flags & RT_FLAG_FMA) != 0;
-  cfg.probe_lds_bytes = (size_t)WAVES_PER_BLOCK * stack_depth * 64 * 4;   // probe_kernel: full-depth stacks only
+  cfg.probe_lds_bytes = lds_bytes_for(stack_depth, p.point_words, WAVES_PER_BLOCK);
   int per_cu = fma ? occupancy_fma(cfg) : occupancy_strict(cfg);
   if (per_cu < 1) return fail(c, RT_ERR_DEVICE, "kernel does not fit on a CU (lds=%zu)", cfg.lds_bytes);
   per_cu = std::min(per_cu, 8);
@@ -871,9 +825,9 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (cfg.grid * wpb > m.queue_waves)
     return fail(c, RT_ERR_LIMIT, "grid exceeds the ray-queue memory");
   if (std::getenv("RT_DEBUG_LAUNCH"))
-    std::fprintf(stderr, "[rt launch] grid %d x %d threads, %d blocks/CU, lds %zu B (scene part %zu), stack rows %d, top=%d lds_top=%d "
+    std::fprintf(stderr, "[rt launch] grid %d x %d threads, %d blocks/CU, lds %zu B (scene part %zu), stack rows %d, "
                  "lds_scene=%d mlight=%d five=%d prune=%d count=%d packets %d\n", cfg.grid, cfg.block, per_cu, cfg.lds_bytes,
-                 cfg.lds_scene_bytes, p.stack_depth, (int)cfg.top, p.lds_top, (int)cfg.lds_scene, (int)cfg.mlight,
+                 cfg.lds_scene_bytes, p.stack_depth, (int)cfg.lds_scene, (int)cfg.mlight,
                  (int)cfg.five_waves, (int)cfg.prune, (int)cfg.count, p.n_packets);
 
   // Refractive packets (a binary ray tree per sample) are handed out pixel by pixel when the
@@ -1000,9 +954,6 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_PROBE_GROUP")) c->probe_group = std::atoi(e);
   if (const char *e = std::getenv("RT_FIVE_WAVES")) c->five_waves_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_DEBUG_CLEAR_BAND")) c->clear_band = (float)std::atof(e);
-  if (const char *e = std::getenv("RT_TOP")) c->top_mode = std::atoi(e);
-  if (const char *e = std::getenv("RT_STACK_CAP")) c->stack_cap = std::atoi(e);
-  if (const char *e = std::getenv("RT_LDS_TOP")) c->lds_top_max = std::max(0, std::atoi(e));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
@@ -1022,7 +973,7 @@ void rt_shutdown(rt_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {c->d_nodes, c->d_prims, c->d_wnodes, c->d_leafbox, c->d_materials12, c->d_prim_src, c->d_wide_src, c->d_level_nodes, c->d_prim_box,
-                  c->d_spheres, c->d_triangles, c->d_materials, c->d_lights, c->d_f6, c->d_scratch, c->d_spill,
+                  c->d_spheres, c->d_triangles, c->d_materials, c->d_lights, c->d_f6, c->d_scratch,
                   c->d_tile_counter, c->d_stats, c->d_rgb, c->d_ids, c->d_acc,
                   c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
@@ -1080,10 +1031,6 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     const int per_wave = ((160 * 1024 / 4) - HOT_WORDS * 4) / WAVES_PER_BLOCK - (point_words_for(sc->n_lights) + 32) * 4;
     const int depth_max = std::min(40, (per_wave / 256) & ~3);   // stack_depth is a multiple of 4 and holds one scratch slot
     wb.cap = std::max(std::max(3, depth_max - 1), rp.max_depth);
-    // A scene whose records cannot fit in a block's LDS whatever the stacks need is rendered from
-    // memory by the TOP builds, whose LDS stacks are short and overflow to memory: nothing to cap.
-    c->big_scene = (rp.prims.size() / 16) * (size_t)(LDS_REC_F4 * 16 + 32) > (size_t)80 * 1024;
-    if (c->big_scene && c->top_mode != 0) wb.cap = std::max(60, rp.max_depth);
   }
   wb.height.assign(rp.nodes.size() / 16, -1);
   if (sc->n_nodes > 0) {

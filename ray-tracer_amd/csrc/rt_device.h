@@ -75,7 +75,7 @@ constexpr int HOT_WORDS = 64;    // LDS words per block for RenderParams::hot an
 constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~88 atomics/us per word)
 // Statistics block (unsigned long long words): [0..15] frame totals (rt_stats order), [16 .. 16 + 4 * 16384)
 // four words per wave (rt_wave_diag), then STATS_DIAG_WORDS of a profiling build's sums: [0..11] phase
-// cycles, [12] steps, [13] active lanes, [16..23] traversal iterations / lane shares, [32..71] deepest
+// cycles, [12] steps, [13] active lanes, [16..23] traversal iterations / lane shares, [24..30] iteration and re-arm cycles, [32..71] deepest
 // stack per closest-hit traversal, [72..111] per shadow ray of the pool, [112..119] wide-node visits
 // with record index < 64 << k (k = 0..6) and all
 constexpr int STATS_WAVE_BASE = 16, STATS_MAX_WAVES = 16384;
@@ -138,11 +138,6 @@ struct RenderParams {
   int point_words;                       // LDS words per wave for the step's shaded points (point_words_for; 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
   int probe_two, probe_group;            // probe_kernel: two rays per multi-pixel packet (else one); single-pixel packets classified per ray
-  // TOP builds (scene in memory, its top records in LDS, short stacks that overflow to memory):
-  int stack_cap, lds_top;                // LDS stack entries per lane (stack_depth = stack_cap + 1); wide records kept in LDS
-  unsigned *spill;                       // per wave: [spill rows][64] stack entries that did not fit
-  unsigned long long spill_stride;       // words per wave
-  int probe_stack_depth, pad1;           // probe_kernel's own (full-depth) stacks
 };
 
 struct LaunchCfg {
@@ -153,7 +148,6 @@ struct LaunchCfg {
   bool lds_scene;           // render from the block's LDS copy of the scene
   bool five_waves;          // the 96-VGPR build: LDS scene of <= 32 KB per block, one light, pruned, uncounted
   bool mlight;              // more than one light: the build with the shadow-ray pool (pruned, uncounted launches)
-  bool top;                 // scene in memory with its top wide records in LDS and short spilling stacks (block = 512 or 1024)
   size_t lds_scene_bytes;   // part of lds_bytes that holds that copy (0 if !lds_scene)
   size_t probe_lds_bytes;   // probe_kernel: the traversal stacks of its own four waves
 };

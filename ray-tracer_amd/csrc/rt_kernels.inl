@@ -65,7 +65,7 @@ struct Counters {
   // record index below 64 << k (k = 0..6) / in all
   unsigned spmax;
   unsigned topk[8];
-  // shader-clock cycles of the wave inside [0] node / [1] leaf iterations of closest-hit traversals, [2], [3] shadow
+  // shader-clock cycles of the wave inside [0] node / [1] leaf iterations of closest-hit traversals, [2], [3] shadow;
   // [4] cycles inside the shadow-ray pool's re-arm blocks, [5] their number, [6] rays they handed out
   unsigned long long tcyc[7];
 #endif
@@ -409,56 +409,6 @@ DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o
   return g > P.clear_band * (fabsf(E) + fabsf(X));
 }
 
-// ---- short per-lane stacks with overflow to memory (TOP builds: scenes too big for LDS) -------
-// The per-lane traversal stack lives in LDS, and LDS is also where the top of the tree is kept
-// for these scenes (render_kernel), so the stack is SHORT: P.stack_cap entries.  Measured on the
-// 100 k-triangle mesh (profiles/r03_c3_diag.txt): 99.5 % of the closest-hit traversals and 99.99 %
-// of the shadow rays never hold more than 8 entries, 99.99 % / 100 % never more than 12; the
-// deepest is 18.  A lane about to outgrow its stack moves the OLDEST half (the far subtrees, popped
-// last) to its column of the wave's overflow area in memory and takes it back, half a stack at a
-// time, when the LDS part has run empty.  Row stack_cap of the LDS stack holds the lane's count of
-// entries in memory: zero whenever the lane has no traversal with spilled entries in progress
-// (`spilled` mirrors "count != 0" so that the common case never reads it).
-template <bool TOP>
-DEVI void stack_room(const RenderParams &P, unsigned *stack, unsigned *ovf, int lane, int &sp, bool &spilled) {
-  if (TOP && sp > P.stack_cap - 3) {   // the step may push three entries
-    const int cap = P.stack_cap, H = cap >> 1;
-    const unsigned ns = stack[cap * 64 + lane];
-    for (int i = 0; i < H; ++i) ovf[(size_t)(ns + i) * 64 + lane] = stack[i * 64 + lane];
-    for (int i = H; i < sp; ++i) stack[(i - H) * 64 + lane] = stack[i * 64 + lane];
-    stack[cap * 64 + lane] = ns + (unsigned)H;
-    sp -= H;
-    spilled = true;
-  }
-}
-// pop the next node, or finish the traversal
-template <bool TOP>
-DEVI void pop_or_stop(const RenderParams &P, unsigned *stack, unsigned *ovf, int lane, int &cur, int &sp, bool &spilled) {
-  if (sp > 0) {
-    --sp;
-    cur = (int)stack[sp * 64 + lane];
-  } else if (TOP && spilled) {
-    const int cap = P.stack_cap, H = cap >> 1;
-    const unsigned ns = stack[cap * 64 + lane] - (unsigned)H;   // (a multiple of H, >= H before)
-    __threadfence_block();  // this lane's earlier stores to its column
-    for (int i = 0; i < H - 1; ++i) stack[i * 64 + lane] = ovf[(size_t)(ns + i) * 64 + lane];
-    cur = (int)ovf[(size_t)(ns + H - 1) * 64 + lane];
-    sp = H - 1;
-    stack[cap * 64 + lane] = ns;
-    spilled = ns != 0u;
-  } else {
-    cur = STOP;
-  }
-}
-// a traversal that ends with entries still on its stack (an occluder found, a re-walk): forget them
-template <bool TOP>
-DEVI void stack_drop(const RenderParams &P, unsigned *stack, int lane, bool &spilled) {
-  if (TOP && spilled) {
-    stack[P.stack_cap * 64 + lane] = 0u;
-    spilled = false;
-  }
-}
-
 // Four box tests from one wide record, range pruning, then the children that remain go on the
 // stack farthest first and the nearest becomes current (or pop, or stop).  The stack writes are
 // unconditional -- a slot above the top is scratch -- so the step has no divergent pushes.
@@ -466,40 +416,21 @@ DEVI void stack_drop(const RenderParams &P, unsigned *stack, int lane, bool &spi
 // wave takes plain divisions and the reference's comparisons (exact at every node).
 // A slot without a child holds an inverted box (min = 2^58, max = -2^58; not counted in S):
 // E~ - X~ is about 2^59 |r~|, far beyond any slop, so it is never entered on the conservative path.
-// TOP: the first P.lds_top records of the table (the top of the tree, breadth first) are read from
-// the block's LDS copy, the others from memory -- per lane.
-template <bool ANY, bool COUNT, bool LDS, bool TOP>
-DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *ovf, int lane, V3 o, V3 d,
-                    const RayBox &rb, const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, bool &spilled,
-                    Counters &cn) {
+template <bool ANY, bool COUNT, bool LDS>
+DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
+                    const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
   const float4 *np = wnode_rec<LDS>(P, sc, cur);
   TOPK_COUNT(cn, cur);
-  stack_room<TOP>(P, stack, ovf, lane, sp, spilled);
+  const float4 rf = np[6];
+  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+  if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
   // range pruning as in node_step
   const float lim = prune_limit(best_t);
   float e0, e1, e2, e3;
   bool h0, h1, h2, h3;
-  int r0, r1, r2, r3;
   if (all_ok) {
-    float4 rf, nx, fx, ny, fy, nz, fz;
-    if (TOP && cur < P.lds_top) {
-      // (an explicit LDS pointer: with two generic pointers the compiler merges the branches into
-      //  flat loads, which take the texture-address path whatever they end up reading)
-      //  flat loads, which take the texture-address path whatever they end up reading; and a plain
-      //  vector type: float4 is a class, whose copy constructor takes a generic reference)
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      typedef const v4f __attribute__((address_space(3))) lds_v4f;
-      lds_v4f *lp = (lds_v4f *)(sc + cur * LDS_WNODE_F4);
-#define RT_LDS_F4(DST, IDX) { const v4f t_ = lp[IDX]; DST = make_float4(t_.x, t_.y, t_.z, t_.w); }
-      RT_LDS_F4(rf, 6)
-      RT_LDS_F4(nx, sg.x) RT_LDS_F4(fx, sg.x ^ 1) RT_LDS_F4(ny, 2 + sg.y) RT_LDS_F4(fy, 2 + (sg.y ^ 1))
-      RT_LDS_F4(nz, 4 + sg.z) RT_LDS_F4(fz, 4 + (sg.z ^ 1))
-#undef RT_LDS_F4
-    } else {
-      rf = np[6];
-      nx = np[sg.x]; fx = np[sg.x ^ 1]; ny = np[2 + sg.y]; fy = np[2 + (sg.y ^ 1)]; nz = np[4 + sg.z]; fz = np[4 + (sg.z ^ 1)];
-    }
-    r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+    const float4 nx = np[sg.x], fx = np[sg.x ^ 1], ny = np[2 + sg.y], fy = np[2 + (sg.y ^ 1)], nz = np[4 + sg.z],
+                 fz = np[4 + (sg.z ^ 1)];
 #define RT_WIDE_CHILD(C_, E_, H_)                                                                           \
   {                                                                                                         \
     const float tx0 = __builtin_fmaf(nx.C_, rb.rx, rb.nx), tx1 = __builtin_fmaf(fx.C_, rb.rx, rb.fx);       \
@@ -522,8 +453,7 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, un
   } else {
     // plain divisions (a zero / denormal / huge direction component, out-of-range origin or scene);
     // a NaN entry or exit is ignored by max / min and never prunes
-    const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5], rf = np[6];
-    r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+    const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5];
     RayDiv rd;
     rd.rx = rd.ry = rd.rz = 1.0f;
     rd.safe = false;
@@ -537,7 +467,6 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, un
     h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
     h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
   }
-  if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
   if (ANY) {
     // "is anything in the way" does not care in which order the boxes are searched: the first
     // child that passed becomes current, the others go on the stack as they come (no sort)
@@ -552,8 +481,11 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, un
     SP_COUNT(cn, sp);
     if (h0 || h1 || h2 || h3) {
       cur = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
+    } else if (sp > 0) {
+      --sp;
+      cur = (int)stack[sp * 64 + lane];
     } else {
-      pop_or_stop<TOP>(P, stack, ovf, lane, cur, sp, spilled);
+      cur = STOP;
     }
     return;
   }
@@ -579,16 +511,19 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, un
   SP_COUNT(cn, sp);
   if (n >= 1) {
     cur = r0;
+  } else if (sp > 0) {
+    --sp;
+    cur = (int)stack[sp * 64 + lane];
   } else {
-    pop_or_stop<TOP>(P, stack, ovf, lane, cur, sp, spilled);
+    cur = STOP;
   }
 }
 
 // One leaf: records first .. first+count-1 (reversed list order), then pop or stop.
-template <bool ANY, bool PRUNE, bool COUNT, bool LDS, bool TOP>
-DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *ovf, int lane, V3 o, V3 d,
-                    const RayBox &rb, bool verify_now, bool &redo, float tlimit, float &best_t, int &best_p, int &cur,
-                    int &sp, bool &spilled, Counters &cn) {
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
+DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
+                    bool verify_now, bool &redo, float tlimit, float &best_t, int &best_p, int &cur, int &sp,
+                    Counters &cn) {
   int first = -1 - cur;
   const float4 *pp = prim_rec<LDS>(P, sc, first);
   int count = __float_as_int(pp[3].w);
@@ -629,18 +564,19 @@ DEVI void leaf_step(const RenderParams &P, const float4 *sc, unsigned *stack, un
   }
   if (ANY && got) {
     cur = STOP;
-    stack_drop<TOP>(P, stack, lane, spilled);
+  } else if (sp > 0) {
+    --sp;
+    cur = (int)stack[sp * 64 + lane];
   } else {
-    pop_or_stop<TOP>(P, stack, ovf, lane, cur, sp, spilled);
+    cur = STOP;
   }
 }
 
 // One inner-node step of either tree: the pruned traversal walks the wide records.
-template <bool ANY, bool PRUNE, bool COUNT, bool LDS, bool TOP>
-DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *ovf, int lane, V3 o, V3 d,
-                     const RayDiv &rd, const RayBox &rb, const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp,
-                     bool &spilled, Counters &cn) {
-  if (PRUNE) wide_step<ANY, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rb, sg, all_safe, best_t, cur, sp, spilled, cn);
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
+DEVI void inner_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayDiv &rd,
+                     const RayBox &rb, const RaySign &sg, bool all_safe, float best_t, int &cur, int &sp, Counters &cn) {
+  if (PRUNE) wide_step<ANY, COUNT, LDS>(P, sc, stack, lane, o, d, rb, sg, all_safe, best_t, cur, sp, cn);
   else node_step<PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, all_safe, best_t, cur, sp, cn);
 }
 
@@ -662,14 +598,12 @@ DEVI void ray_setup(const RenderParams &P, V3 o, V3 d, RayDiv &rd, RayBox &rb, b
   }
 }
 
-template <bool ANY, bool PRUNE, bool COUNT, bool LDS, bool TOP = false>
-DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *ovf, int lane, bool active, V3 o,
-                   V3 d, float tlimit, float &best_t, int &best_p, Counters &cn) {
-  static_assert(!TOP || (PRUNE && !LDS), "the on-chip tree top belongs to the pruned traversal of scenes in memory");
+template <bool ANY, bool PRUNE, bool COUNT, bool LDS>
+DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, bool active, V3 o, V3 d,
+                   float tlimit, float &best_t, int &best_p, Counters &cn) {
   best_t = ANY ? tlimit : INFINITY;
   best_p = -1;
   int sp = 0;
-  bool spilled = false;
   int cur = (active && P.has_root) ? 0 : STOP;
   RayDiv rd;
   RayBox rb;
@@ -696,13 +630,13 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, uns
         if (at_node >= at_leaf) {
           if (cur >= 0) {
             DIV_COUNT(cn, ANY ? 2 : 0);
-            inner_step<ANY, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, spilled, cn);
+            inner_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
           }
           IT_T1(cn, ANY ? 2 : 0);
         } else {
           if (cur < 0 && cur != STOP) {
             DIV_COUNT(cn, ANY ? 3 : 1);
-            leaf_step<ANY, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, spilled, cn);
+            leaf_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, cn);
           }
           IT_T1(cn, ANY ? 3 : 1);
         }
@@ -714,11 +648,11 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, uns
       while (cur != STOP) {
         while (cur >= 0) {
           DIV_COUNT(cn, ANY ? 2 : 0);
-          inner_step<ANY, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, spilled, cn);
+          inner_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, best_t, cur, sp, cn);
         }
         if (cur != STOP) {
           DIV_COUNT(cn, ANY ? 3 : 1);
-          leaf_step<ANY, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, spilled, cn);
+          leaf_step<ANY, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, false, redo_unused, tlimit, best_t, best_p, cur, sp, cn);
         }
       }
     }
@@ -780,8 +714,8 @@ DEVI bool light_matters(V3 l_dir, V3 n, V3 v, float phong) {
 // set-up code is issued for the whole wave whoever needs it.
 // LDS, 64 words each: x, y, z, s0, s1, occlusion mask (indexed by the owner's lane), hand-out
 // table, per-light 64-bit masks of the points that need the light.
-template <bool PRUNE, bool COUNT, bool LDS, bool TOP>
-DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *ovf, unsigned *pts, int lane,
+template <bool PRUNE, bool COUNT, bool LDS>
+DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *stack, unsigned *pts, int lane,
                             unsigned long long lt_mask, bool hit, V3 pt, float s0, float s1, unsigned need,
                             int hi, int lo, Counters &cn) {
   if (!P.has_root) return 0;
@@ -808,7 +742,6 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
   int cl = hi - lo;                // current light (bit index); its unserved points in `rm`
   unsigned long long rm = 0ull;    // both wave-uniform
   int cur = STOP, sp = 0, owner = 0, bit = 0;
-  bool spilled = false;
   bool armed = false;  // (profiling build: this lane has taken a ray of the pool)
   (void)armed;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -865,7 +798,7 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
     if (at_node >= at_leaf) {
       if (cur >= 0) {
         DIV_COUNT(cn, 2);
-        inner_step<true, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rd, rb, sg, all_safe, tlimit, cur, sp, spilled, cn);
+        inner_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rd, rb, sg, all_safe, tlimit, cur, sp, cn);
       }
       IT_T1(cn, 2);
     } else if (cur < 0 && cur != STOP) {
@@ -873,10 +806,9 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       float bt = tlimit;
       int bp = -1;
       bool redo;
-      leaf_step<true, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, o, d, rb, all_safe, redo, tlimit, bt, bp, cur, sp, spilled, cn);
+      leaf_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, all_safe, redo, tlimit, bt, bp, cur, sp, cn);
       if (bp >= 0) atomicOr(&occl[owner], 1u << bit);
       if (redo) {  // no clear verdict for the occluder's leaf box: this ray again, on the exact path
-        stack_drop<TOP>(P, stack, lane, spilled);
         safe = false;
         sp = 0;
         cur = 0;
@@ -1101,11 +1033,7 @@ DEVI int fetch_packet(const RenderParams &P, int lane, PacketSrc &ps) {
 // WPS waves per SIMD the registers are budgeted for: 4 (128 VGPRs), or 5 (96 VGPRs, a dozen
 // spilled) for the small-scene single-light build, where the fifth wave buys more than the
 // spills cost once frames are pipelined (c2 2.39 -> 2.34 ms); everywhere else 5 measured slower.
-// TOP (scenes in memory, pruned): the block keeps the first P.lds_top wide records -- the top of
-// the tree, which serves most node visits (mesh workload: 512 records of 22 600 take 62 % of them) --
-// in LDS, beside SHORT traversal stacks that overflow to memory (stack_room).  One 16-wave block per
-// CU (or two 8-wave blocks) so that the CU's waves share one copy.
-template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT, int WPB = WAVES_PER_BLOCK, int WPS = RT_WAVES_PER_SIMD, bool TOP = false>
+template <bool PRUNE, bool COUNT, bool LDS, bool MLIGHT, int WPB = WAVES_PER_BLOCK, int WPS = RT_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParams P) {
   extern __shared__ __align__(16) unsigned lds[];
   const int lane = threadIdx.x & 63;
@@ -1118,7 +1046,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   const float4 *sc = reinterpret_cast<const float4 *>(lds);
   // (LDS builds also hold the material table behind the records: per-lane gathers of the
   //  12 material floats then cost an LDS read instead of a trip through TA/L1)
-  const int rec_words = LDS ? P.lds_rec_f4 * 4 : (TOP ? P.lds_top * LDS_WNODE_F4 * 4 : 0);  // wide or binary records, primitive records, leaf boxes; TOP: the tree's top records
+  const int rec_words = LDS ? P.lds_rec_f4 * 4 : 0;  // wide or binary records, primitive records, leaf boxes
   const int mat_words = LDS ? P.n_materials * MAT_F : 0;
   const int scene_words = rec_words + mat_words;
   const float *ldsM = reinterpret_cast<const float *>(lds + rec_words);
@@ -1152,22 +1080,12 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   // the block's copy of the per-frame vector constants and of the first light (rt_device.h)
   const float *hotL = reinterpret_cast<const float *>(lds + scene_words);
   if (!LDS) {
-    if (TOP) {
-      float4 *dst = reinterpret_cast<float4 *>(lds);
-      for (int i = threadIdx.x; i < P.lds_top * 7; i += 64 * WPB) {
-        const int rec = i / 7, part = i - rec * 7;
-        dst[rec * LDS_WNODE_F4 + part] = P.wnodes[(size_t)rec * WNODE_F4 + part];
-      }
-    }
     if (threadIdx.x < 24) lds[scene_words + threadIdx.x] = __float_as_uint(P.hot[threadIdx.x]);
     if (threadIdx.x >= 32 && threadIdx.x < 44 && P.n_lights > 0)
       lds[scene_words + threadIdx.x] = __float_as_uint(P.lights[threadIdx.x - 32]);
     __syncthreads();
   }
   unsigned *stack = lds + scene_words + HOT_WORDS + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
-  // TOP: the stack holds P.stack_cap entries; its last row counts the lane's entries in memory (stack_room)
-  unsigned *ovf = TOP ? P.spill + gwave * P.spill_stride : nullptr;
-  if (TOP) stack[P.stack_cap * 64 + lane] = 0u;
   unsigned *pts = stack + P.stack_depth * 64;  // shaded points of the step (shadow_lights; MLIGHT builds)
   unsigned *cnt = pts + P.point_words;           // cnt[L], L = 2..max_depth : rays queued at level L
 
@@ -1317,7 +1235,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
     // ---- raytrace (RayTracer.hs:55-71): closest hit ----------------------------------
     float t;
     int p;
-    traverse<false, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, active, o, d, 0.0f, t, p, cn);
+    traverse<false, PRUNE, COUNT, LDS>(P, sc, stack, lane, active, o, d, 0.0f, t, p, cn);
     const bool hit = active && p >= 0;
     PH_MARK(1);
     n_hits += __popcll(__ballot(hit));
@@ -1373,7 +1291,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
         }
         PH_MARK(2);
         const unsigned occluded =
-            shadow_lights<PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, pts, lane, lt_mask, hit, pt, s0, s1, need, hi, lo, cn);
+            shadow_lights<PRUNE, COUNT, LDS>(P, sc, stack, pts, lane, lt_mask, hit, pt, s0, s1, need, hi, lo, cn);
         PH_MARK(3);
         if (need) {
           // the point and its light-sample coordinates were parked in LDS for the pool: take them
@@ -1418,7 +1336,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       float st;
       int sprim;
       PH_MARK(2);
-      traverse<true, PRUNE, COUNT, LDS, TOP>(P, sc, stack, ovf, lane, need, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
+      traverse<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, need, pt, l_dir, max_d, st, sprim, cn);  // inShadow :231-235
       PH_MARK(3);
       n_shadow += __popcll(__ballot(need));
       if (need && sprim < 0) {
@@ -1679,7 +1597,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
   __shared__ unsigned hist[PROBE_CLASSES];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  unsigned *stack = lds + (size_t)wib * (P.probe_stack_depth * 64);  // full depth: never spills
+  unsigned *stack = lds + (size_t)wib * (P.stack_depth * 64 + P.point_words + 32);
   if (threadIdx.x < PROBE_CLASSES) hist[threadIdx.x] = 0;
   __syncthreads();
   const int span = P.probe_span;  // packets per block (multiple of 256)
@@ -1708,7 +1626,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const RenderParams P) {
     }
     float t;
     int p;
-    traverse<false, PRUNE, false, false>(P, nullptr, stack, nullptr, lane, inside, o, d, 0.0f, t, p, cn);
+    traverse<false, PRUNE, false, false>(P, nullptr, stack, lane, inside, o, d, 0.0f, t, p, cn);
     int cls = 0;
     if (inside && p >= 0) {
       int mat = __float_as_int(P.prims[(size_t)p * PRIM_F4 + 3].y);
@@ -1888,22 +1806,9 @@ static int occupancy_k(K kernel, int block, size_t lds_bytes) {
 // The instantiation the host's choices (rt_api.hip launch()) select; F is called with the kernel
 // and the dynamic LDS it needs, so that launch and occupancy query cannot disagree.
 template <class F>
-static auto with_render_kernel(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, bool top, int block,
+static auto with_render_kernel(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block,
                                size_t lds_bytes, size_t lds_scene_bytes, F f) {
   const size_t no_scene = lds_bytes - lds_scene_bytes;
-  if (top) {  // scene in memory, its top records on chip (host: pruned, uncounted launches only); lds_bytes includes them
-    if (block == 1024) {
-      if (mlight) return f(&render_kernel<true, false, false, true, 16, 4, true>, lds_bytes);
-      return f(&render_kernel<true, false, false, false, 16, 4, true>, lds_bytes);
-    }
-    if (block == 512) {
-      if (mlight) return f(&render_kernel<true, false, false, true, 8, 4, true>, lds_bytes);
-      return f(&render_kernel<true, false, false, false, 8, 4, true>, lds_bytes);
-    }
-    // (experiments: 4-wave blocks, four or five waves per SIMD)
-    if (five_waves) return f(&render_kernel<true, false, false, true, 4, 5, true>, lds_bytes);
-    return f(&render_kernel<true, false, false, true, 4, 4, true>, lds_bytes);
-  }
   if (block == 512) {  // LDS scene shared by two 8-wave blocks per CU; pruned, uncounted (host only picks it then)
     if (mlight) return f(&render_kernel<true, false, true, true, 8>, lds_bytes);
     return f(&render_kernel<true, false, true, false, 8>, lds_bytes);
@@ -1933,7 +1838,7 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
     hipLaunchKernelGGL(order_kernel, dim3(p.probe_blocks), dim3(256), 0, s, p);
   }
   if (cfg.ev_k0) (void)hipEventRecord(cfg.ev_k0, s);  // around the trace/shade kernel alone
-  with_render_kernel(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.top, cfg.block, cfg.lds_bytes,
+  with_render_kernel(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
                      cfg.lds_scene_bytes, [&](auto kernel, size_t lds) {
                        launch_k(kernel, cfg.grid, cfg.block, lds, s, p);
                        return 0;
@@ -1948,9 +1853,9 @@ static void launch(const RenderParams &p, const LaunchCfg &cfg, hipStream_t s) {
   }
 }
 
-static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, bool top, int block,
-                     size_t lds_bytes, size_t lds_scene_bytes) {
-  return with_render_kernel(prune, count, lds_scene, mlight, five_waves, top, block, lds_bytes, lds_scene_bytes,
+static int occupancy(bool prune, bool count, bool lds_scene, bool mlight, bool five_waves, int block, size_t lds_bytes,
+                     size_t lds_scene_bytes) {
+  return with_render_kernel(prune, count, lds_scene, mlight, five_waves, block, lds_bytes, lds_scene_bytes,
                             [&](auto kernel, size_t lds) { return occupancy_k(kernel, block, lds); });
 }
 

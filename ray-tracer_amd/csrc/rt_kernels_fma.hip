@@ -10,7 +10,7 @@ void launch_render_fma(const RenderParams &p, const LaunchCfg &cfg, hipStream_t 
   fma::launch(p, cfg, s);
 }
 int occupancy_fma(const LaunchCfg &cfg) {
-  return fma::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.top, cfg.block, cfg.lds_bytes,
+  return fma::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
                            cfg.lds_scene_bytes);
 }
 }  // namespace rtdev

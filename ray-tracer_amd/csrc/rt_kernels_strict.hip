@@ -12,7 +12,7 @@ void launch_material_prep(const float *materials12, float *materials_dev, int n,
   if (n > 0) hipLaunchKernelGGL(strict::material_prep_kernel, dim3((n + 63) / 64), dim3(64), 0, s, materials12, materials_dev, n);
 }
 int occupancy_strict(const LaunchCfg &cfg) {
-  return strict::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.top, cfg.block, cfg.lds_bytes,
+  return strict::occupancy(cfg.prune, cfg.count, cfg.lds_scene, cfg.mlight, cfg.five_waves, cfg.block, cfg.lds_bytes,
                            cfg.lds_scene_bytes);
 }
 }  // namespace rtdev
