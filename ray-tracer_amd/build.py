@@ -3,6 +3,7 @@
     librt_host.so    g++     host-side scene / BVH / sample-table producer
     librt_mi355x.so  hipcc   the C-ABI device library (gfx950); kernels compiled twice,
                              -ffp-contract=off (strict) and -ffp-contract=fast (fma)
+    librt_mi355x_dbg.so      the same with -DRT_DEBUG_KNOBS (test-only knobs in the hot loop)
 """
 from __future__ import annotations
 
@@ -89,6 +90,8 @@ def build_harness(force=False):
 def build_all(force=False):
     h, d = build_host(force), build_device(force)
     build_harness(force)
+    # the RT_DEBUG_KNOBS variant (tests only: tests/test_gpu_parity.py::test_exact_verdicts_catch_conservative_errors)
+    build_device(force, ["RT_DEBUG_KNOBS"], "_dbg")
     return h, d
 
 

@@ -98,6 +98,10 @@ struct rt_ctx {
   // DOF frame 4.80 -> 4.71 ms; 8 and 16 are no better).  RT_PROBE_TWO, RT_PROBE_GROUP override.
   int probe_two = 0, probe_group = 4;
   int split_mode = 0;   // RT_SPLIT_REFRACTIVE: 0 off (default: measured no gain), 1 on, -1 auto; never changes a pixel
+  float box_slop_scale = 1.0f;  // RT_DEBUG_BOX_SLOP: inflates the conservative box tests' slop (tests; >= 1)
+  int debug_unsafe_mod = 0;     // RT_DEBUG_UNSAFE_MOD
+  int debug_no_range = 0;       // RT_DEBUG_NO_RANGE_PRUNE
+  int trust_tree = 0;           // RT_DEBUG_TRUST_TREE: skip the check that leaf boxes bound their objects (tests)
 };
 
 // ---- the library's static work memory (rt_render_static_async) --------------------------
@@ -706,6 +710,10 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   p.boxes_safe = c->boxes_safe;
   p.box_absmax = c->box_absmax;
   p.clear_band = c->clear_band;
+  p.slop_lds = 4.76837158203125e-07f * c->box_slop_scale;   // 2^-21
+  p.slop_mem = 9.5367431640625e-07f * c->box_slop_scale;    // 2^-20
+  p.debug_unsafe_mod = c->debug_unsafe_mod;
+  p.debug_no_range = c->debug_no_range;
   p.W = cam.img_w;
   p.H = cam.img_h;
   p.max_depth = cam.max_depth;
@@ -954,6 +962,10 @@ int rt_init(int device, rt_ctx **out) {
   if (const char *e = std::getenv("RT_PROBE_GROUP")) c->probe_group = std::atoi(e);
   if (const char *e = std::getenv("RT_FIVE_WAVES")) c->five_waves_mode = std::atoi(e);
   if (const char *e = std::getenv("RT_DEBUG_CLEAR_BAND")) c->clear_band = (float)std::atof(e);
+  if (const char *e = std::getenv("RT_DEBUG_BOX_SLOP")) c->box_slop_scale = std::max(1.0f, (float)std::atof(e));
+  if (const char *e = std::getenv("RT_DEBUG_UNSAFE_MOD")) c->debug_unsafe_mod = std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("RT_DEBUG_NO_RANGE_PRUNE")) c->debug_no_range = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RT_DEBUG_TRUST_TREE")) c->trust_tree = std::atoi(e) != 0;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
@@ -1088,6 +1100,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   c->boxes_safe = 1;
   c->box_absmax = 0.0f;
   for (int i = 0; i < sc->n_nodes && c->boxes_safe; ++i) {
+    if (!rp.seen[i]) continue;
     const float *b = &sc->nodes[i].xmin;
     for (int k = 0; k < 6; ++k) {
       float a = std::fabs(b[k]);
@@ -1100,12 +1113,41 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   c->nested = true;
   for (int i = 0; i < sc->n_nodes && c->nested; ++i) {
     const rt_bvh_node &n = sc->nodes[i];
-    if (n.left < 0) continue;
+    // (only nodes the tree reaches: Repack::visit has range-checked their children; an unreachable
+    //  node may hold anything)
+    if (!rp.seen[i] || n.left < 0) continue;
     const float *pb = &n.xmin;
     for (int k = 0; k < 2; ++k) {
       const float *cb = &sc->nodes[k ? n.right : n.left].xmin;
       for (int a = 0; a < 3; ++a)
         if (!(cb[2 * a] >= pb[2 * a] && cb[2 * a + 1] <= pb[2 * a + 1])) c->nested = false;
+    }
+  }
+  // Does every leaf box bound its objects?  (sahBVH's do: a leaf's box is the fold of its objects'
+  // toBox, BoundingVolumeHierarchy.hs:50-51,178-189.)  hitsBox is a LINE test: with a leaf box that cuts its
+  // object short the reference tests the object for every ray whose line meets the box, wherever the
+  // hit lies -- range pruning (entry beyond the closest hit, exit behind the origin) would lose such
+  // hits.  Such a tree is walked the reference's way as well.
+  for (int i = 0; i < sc->n_nodes && c->nested && !c->trust_tree; ++i) {
+    const rt_bvh_node &n = sc->nodes[i];
+    if (!rp.seen[i] || n.left >= 0) continue;
+    const float *lb = &n.xmin;
+    const long first = -1L - (long)n.left;
+    for (int k = 0; k < n.right && c->nested; ++k) {
+      const uint32_t r = sc->leaf_refs[first + k];
+      for (int a = 0; a < 3 && c->nested; ++a) {
+        float lo, hi;
+        if (r & RT_REF_TRIANGLE) {
+          const rt_triangle &t = sc->triangles[RT_REF_INDEX(r)];
+          lo = std::min(std::min(t.a[a], t.b[a]), t.c[a]);
+          hi = std::max(std::max(t.a[a], t.b[a]), t.c[a]);
+        } else {
+          const rt_sphere &s = sc->spheres[r];
+          lo = s.center[a] - s.radius;
+          hi = s.center[a] + s.radius;
+        }
+        if (!(lb[2 * a] <= lo && hi <= lb[2 * a + 1])) c->nested = false;
+      }
     }
   }
   c->have_scene = true;

@@ -138,6 +138,8 @@ struct RenderParams {
   int point_words;                       // LDS words per wave for the step's shaded points (point_words_for; 0 with one light)
   int rearm_min;                         // shadow-ray pool: idle lanes that trigger a re-arm (RT_REARM_MIN)
   int probe_two, probe_group;            // probe_kernel: two rays per multi-pixel packet (else one); single-pixel packets classified per ray
+  float slop_lds, slop_mem;              // relative slop of the conservative box tests: 2^-21 (scenes in LDS), 2^-20 (in memory); RT_DEBUG_BOX_SLOP scales them
+  int debug_unsafe_mod, debug_no_range;  // RT_DEBUG_UNSAFE_MOD = k: every k-th ray is sent down the plain-division path; RT_DEBUG_NO_RANGE_PRUNE (tests)
 };
 
 struct LaunchCfg {

@@ -341,6 +341,16 @@ DEVI void cswap(float &ka, int &ra, float &kb, int &rb) {
 //    the reference accepting implies E~ <= X~: 6 FMAs, max3, min3 and three comparisons per box.
 // No overflow or NaN on this path: |d| in [2^-40, 2^40], |o| and box coordinates <= 2^59 (other
 // rays and scenes take the plain-division path below, which is exact at every node).
+// The slop of the conservative tests: 2^-21 relative (scenes in LDS), 2^-20 (scenes in memory).  The
+// RT_DEBUG_KNOBS build (librt_mi355x_dbg.so, tests only) takes them from the launch parameters so
+// that RT_DEBUG_BOX_SLOP can make the conservative tests err on purpose.
+#ifdef RT_DEBUG_KNOBS
+#define RT_SLOP_LDS(P) ((P).slop_lds)
+#define RT_SLOP_MEM(P) ((P).slop_mem)
+#else
+#define RT_SLOP_LDS(P) 4.76837158203125e-07f
+#define RT_SLOP_MEM(P) 9.5367431640625e-07f
+#endif
 struct RayBox {
   float rx, ry, rz;     // ~ 1 / d
   float nx, ny, nz;     // addend of the near planes: -(o * r~) [- delta]
@@ -359,12 +369,12 @@ DEVI RayBox make_raybox(const RenderParams &P, V3 o, V3 d) {
     b.nx = b.fx = -ox;
     b.ny = b.fy = -oy;
     b.nz = b.fz = -oz;
-    b.b0 = 2.384185791015625e-07f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    b.b0 = (0.5f * RT_SLOP_LDS(P)) * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));   // 2^-22 max |or~|
   } else {
     const float S = P.box_absmax;
-    const float dx = (9.5367431640625e-07f * (S + fabsf(o.x))) * fabsf(b.rx);
-    const float dy = (9.5367431640625e-07f * (S + fabsf(o.y))) * fabsf(b.ry);
-    const float dz = (9.5367431640625e-07f * (S + fabsf(o.z))) * fabsf(b.rz);
+    const float dx = (RT_SLOP_MEM(P) * (S + fabsf(o.x))) * fabsf(b.rx);
+    const float dy = (RT_SLOP_MEM(P) * (S + fabsf(o.y))) * fabsf(b.ry);
+    const float dz = (RT_SLOP_MEM(P) * (S + fabsf(o.z))) * fabsf(b.rz);
     b.nx = -ox - dx; b.ny = -oy - dy; b.nz = -oz - dz;
     b.fx = dx - ox;  b.fy = dy - oy;  b.fz = dz - oz;
     b.b0 = 0.0f;
@@ -416,6 +426,15 @@ DEVI bool leaf_box_clear(const RenderParams &P, const float4 *sc, int prim, V3 o
 // wave takes plain divisions and the reference's comparisons (exact at every node).
 // A slot without a child holds an inverted box (min = 2^58, max = -2^58; not counted in S):
 // E~ - X~ is about 2^59 |r~|, far beyond any slop, so it is never entered on the conservative path.
+// (RT_DEBUG_KNOBS build, RT_DEBUG_NO_RANGE_PRUNE: no range pruning -- a test tree whose leaf boxes do not
+//  bound their objects breaks what the pruning rests on, not what the exact verdicts rest on)
+#ifdef RT_DEBUG_KNOBS
+#define RT_LIM(P, t) ((P).debug_no_range ? INFINITY : prune_limit(t))
+#define RT_BEHIND(P) ((P).debug_no_range ? -INFINITY : BEHIND)
+#else
+#define RT_LIM(P, t) prune_limit(t)
+#define RT_BEHIND(P) BEHIND
+#endif
 template <bool ANY, bool COUNT, bool LDS>
 DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, int lane, V3 o, V3 d, const RayBox &rb,
                     const RaySign &sg, bool all_ok, float best_t, int &cur, int &sp, Counters &cn) {
@@ -425,7 +444,8 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
   int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
   if (COUNT) cn.box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
   // range pruning as in node_step
-  const float lim = prune_limit(best_t);
+  const float lim = RT_LIM(P, best_t);
+  const float behind = RT_BEHIND(P);
   float e0, e1, e2, e3;
   bool h0, h1, h2, h3;
   if (all_ok) {
@@ -439,10 +459,10 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
     E_ = fmaxf(fmaxf(tx0, ty0), tz0);                                                                       \
     const float X_ = fminf(fminf(tx1, ty1), tz1);                                                           \
     if (LDS) {                                                                                              \
-      const float thr = __builtin_fmaf(fabsf(E_) + fabsf(X_), 4.76837158203125e-07f, rb.b0);                \
-      H_ = (E_ - X_ <= thr) && !(E_ - thr > lim || X_ + thr < BEHIND);                                      \
+      const float thr = __builtin_fmaf(fabsf(E_) + fabsf(X_), RT_SLOP_LDS(P), rb.b0);                       \
+      H_ = (E_ - X_ <= thr) && !(E_ - thr > lim || X_ + thr < behind);                                      \
     } else {                                                                                                \
-      H_ = (E_ <= X_) && !(E_ > lim || X_ < BEHIND);                                                        \
+      H_ = (E_ <= X_) && !(E_ > lim || X_ < behind);                                                        \
     }                                                                                                       \
   }
     RT_WIDE_CHILD(x, e0, h0)
@@ -462,10 +482,10 @@ DEVI void wide_step(const RenderParams &P, const float4 *sc, unsigned *stack, in
     h1 = hits_box<false>(o, d, rd, a0.y, a1.y, a2.y, a3.y, a4.y, a5.y, e1, x1);
     h2 = hits_box<false>(o, d, rd, a0.z, a1.z, a2.z, a3.z, a4.z, a5.z, e2, x2);
     h3 = hits_box<false>(o, d, rd, a0.w, a1.w, a2.w, a3.w, a4.w, a5.w, e3, x3);
-    h0 = h0 && r0 != REF_NONE && !(e0 > lim || x0 < BEHIND);
-    h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < BEHIND);
-    h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < BEHIND);
-    h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < BEHIND);
+    h0 = h0 && r0 != REF_NONE && !(e0 > lim || x0 < behind);
+    h1 = h1 && r1 != REF_NONE && !(e1 > lim || x1 < behind);
+    h2 = h2 && r2 != REF_NONE && !(e2 > lim || x2 < behind);
+    h3 = h3 && r3 != REF_NONE && !(e3 > lim || x3 < behind);
   }
   if (ANY) {
     // "is anything in the way" does not care in which order the boxes are searched: the first
@@ -609,6 +629,9 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
   RayBox rb;
   bool safe;
   ray_setup<PRUNE, LDS>(P, o, d, rd, rb, safe);
+#ifdef RT_DEBUG_KNOBS
+  if (P.debug_unsafe_mod && lane % P.debug_unsafe_mod == 0) safe = false;  // (tests)
+#endif
   const RaySign sg = make_sign(d);
   // one unsafe lane sends the whole wave down the plain-division path (rare: a zero or
   // denormal direction component, or an out-of-range scene)
@@ -780,6 +803,9 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
         light_ray(P.lights + (size_t)(lo + bit) * 12, o, __uint_as_float(pts[3 * 64 + owner]), __uint_as_float(pts[4 * 64 + owner]), d,
                   tlimit);
         ray_setup<PRUNE, LDS>(P, o, d, rd, rb, safe);
+#ifdef RT_DEBUG_KNOBS
+        if (P.debug_unsafe_mod && (owner + bit) % P.debug_unsafe_mod == 0) safe = false;  // (tests: exact and conservative rays in one wave)
+#endif
         sg = make_sign(d);
         sp = 0;
         cur = 0;
@@ -806,7 +832,12 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
       float bt = tlimit;
       int bp = -1;
       bool redo;
-      leaf_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, all_safe, redo, tlimit, bt, bp, cur, sp, cn);
+      // verify_now is PER LANE: a ray that set out on the conservative path asks for the exact verdict of
+      // its occluder's leaf box even after a neighbour (re-armed later with a zero direction component,
+      // or redoing itself) has sent the whole wave to the plain-division node tests -- the leaves it
+      // holds were entered on conservative verdicts.  A ray that has been exact from the root
+      // (safe == false when it was armed or redone) never asks.
+      leaf_step<true, PRUNE, COUNT, LDS>(P, sc, stack, lane, o, d, rb, safe, redo, tlimit, bt, bp, cur, sp, cn);
       if (bp >= 0) atomicOr(&occl[owner], 1u << bit);
       if (redo) {  // no clear verdict for the occluder's leaf box: this ray again, on the exact path
         safe = false;

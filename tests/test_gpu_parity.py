@@ -2,6 +2,7 @@
 seeded inputs.  The oracle is a restatement of the reference (PARITY UNPINNED: the
 reference has no tests or golden vectors, see oracle/rt_oracle.c)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -734,6 +735,61 @@ def test_every_traversal_rewalks_on_the_exact_path(rt, oracle, name, w, h, rpp, 
     assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
            (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
     check_image(rt, g_rgb, o_rgb)
+
+
+def _knobs_child(name, w, h, rpp, lib, **env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, RT_MI355X_LIB=os.path.join(root, "ray-tracer_amd", "lib", lib), **env)
+    assert os.path.exists(e["RT_MI355X_LIB"]), f"{lib} is missing (__graft_entry__.build() makes it)"
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "knobs_child.py"), name, str(w), str(h), str(rpp)],
+                       env=e, capture_output=True, text=True, timeout=150)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["lib"] == lib
+    return out
+
+
+@pytest.mark.parametrize("name,w,h,rpp", [("bench1", 96, 72, 16), ("bench3", 96, 72, 4), ("mesh:3000", 96, 54, 4)])
+def test_exact_verdicts_catch_conservative_errors(rt, name, w, h, rpp):
+    """The pruned traversal may enter any box on the way down (conservative tests) because the leaf
+    box of a primitive that WINS gets the reference's own verdict (leaf_box_clear, else a second
+    walk on the plain-division path).  Here the conservative tests are made to err on purpose -- the
+    RT_DEBUG_KNOBS build with RT_DEBUG_BOX_SLOP = 2^15 (a slop of 1.5-3 % instead of 2^-21 / 2^-20) --
+    on a tree whose leaf boxes are cut down until they no longer bound their objects, so that a ray
+    let into a leaf by the inflated test meets an object the reference never tests; and every fifth
+    ray is sent down the plain-division path (RT_DEBUG_UNSAFE_MOD), which puts exact and conservative
+    rays into one wave of the shadow-ray pool: a lane that holds conservatively entered leaves must
+    still ask for the exact verdict after a neighbour has switched the wave's node tests to plain
+    divisions (with the wave-wide switch as the condition, the mesh case came out with 5 wrong
+    pixels).  Range pruning is switched off for this tree: it rests on boxes that bound their
+    objects, which is not what is tested here (RT_DEBUG_TRUST_TREE keeps rt_upload_scene from
+    sending the tree to the reference-visit mode for that very reason).  Ids, ray counts and the
+    image must equal the oracle's on the same tree."""
+    knobs = dict(RT_DEBUG_UNSAFE_MOD="5", RT_DEBUG_NO_RANGE_PRUNE="1", RT_DEBUG_TRUST_TREE="1")
+    plain = _knobs_child(name, w, h, rpp, "librt_mi355x_dbg.so", RT_DEBUG_BOX_SLOP="1", **knobs)
+    forced = _knobs_child(name, w, h, rpp, "librt_mi355x_dbg.so", RT_DEBUG_BOX_SLOP="32768", **knobs)
+    assert forced["ids_changed_by_shrinking"] > 0, "the shrunken leaf boxes hide nothing"
+    # (the knob took effect: the inflated tests let rays into more boxes)
+    assert forced["box_tests"] + forced["object_tests"] > plain["box_tests"] + plain["object_tests"], (forced, plain)
+    for o in (plain, forced):
+        assert o["id_mismatches"] == 0, o
+        assert o["rays_gpu"] == o["rays_oracle"], o
+        assert o["max_delta8"] <= 1 and o["pixels_off"] == 0, o
+
+
+@pytest.mark.parametrize("name,w,h,rpp", [("bench1", 96, 72, 16), ("mesh:3000", 96, 54, 4)])
+def test_tree_whose_leaf_boxes_cut_their_objects_short(rt, name, w, h, rpp):
+    """hitsBox is a line test, so the reference tests a leaf's objects for every ray whose LINE meets
+    the leaf's box, wherever the hit lies; the pruned traversal's range pruning rests on boxes that
+    bound their objects (sahBVH's do).  A host tree with leaf boxes cut short is noticed by
+    rt_upload_scene and walked the reference's way: the shipped library must agree with the oracle."""
+    o = _knobs_child(name, w, h, rpp, "librt_mi355x.so")
+    assert o["ids_changed_by_shrinking"] > 0
+    assert o["id_mismatches"] == 0 and o["rays_gpu"] == o["rays_oracle"], o
+    assert o["max_delta8"] <= 1 and o["pixels_off"] == 0, o
 
 
 def test_tree_whose_boxes_do_not_nest_is_walked_the_reference_way(rt, oracle):
