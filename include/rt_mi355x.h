@@ -232,9 +232,9 @@ int rt_render(rt_ctx *ctx, uint32_t flags, float *rgb_out, uint32_t *primary_hit
 int rt_render_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_primary_hit_ids,
                     void *hip_stream);
 
-/* rt_render_async for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  NO counterpart in the
- * reference.  Same inputs, outputs and results (bit for bit) as rt_render_async, but every
+/* rt_render_async for callers that cannot allocate device memory: tight serving loops, harnesses
+ * that forbid hipMalloc, code that must not trigger an allocation at this point.  NO counterpart
+ * in the reference.  Same inputs, outputs and results (bit for bit) as rt_render_async, but every
  * per-frame work buffer (pixel sums, ticket counters, packet order, per-wave ray queues,
  * statistics) lives in a static device array of the library, at most 32 MiB per GPU, held
  * from library load to process end, instead of the context's hipMalloc'ed buffers: the call
@@ -244,7 +244,12 @@ int rt_render_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_prima
  * most 512 persistent waves, so it is slower than rt_render_async on large frames.  The
  * scene, camera and samples are set up beforehand with the usual calls (which do allocate).
  * ALL calls on one GPU -- from any context -- share that GPU's array: calls that overlap on a
- * GPU race; serialise them (one stream, or events).  rt_collect works as usual afterwards. */
+ * GPU race; serialise them (one stream, or events).  rt_collect works as usual afterwards, but
+ * the statistics block is part of the shared array: it is valid until the NEXT static call on
+ * that GPU, whichever context makes it.  Allocating nothing is all this call promises: it still
+ * waits for the context's previous launch when that went to another stream, and with timing on
+ * (rt_set_timing) it records events -- neither is capture-safe, and it has not been run under
+ * stream capture. */
 int rt_render_static_async(rt_ctx *ctx, uint32_t flags, float *d_rgb, uint32_t *d_primary_hit_ids,
                            void *hip_stream);
 
@@ -315,7 +320,13 @@ int rt_abi_version(void);
  * data path on fewer GPUs): the exchange then uses device-to-device copies instead of RCCL, which
  * refuses duplicate devices.  RCCL is loaded at run time by this call only.
  * On failure *out is still set when possible, so that rt_multi_last_error can be read; free it
- * with rt_multi_shutdown. */
+ * with rt_multi_shutdown.  A lone GPU (n_gpus = 1) works without RCCL installed (it has nobody to
+ * exchange with); with RCCL it sends itself a few bytes per frame so that the binding is exercised.
+ * State: rt_multi_upload_scene / _refit / _set_camera / _set_samples / _set_concurrency return
+ * RT_ERR_STATE while a frame is in flight (between rt_multi_submit and rt_multi_wait).
+ * NOTE: the N > 1 RCCL exchange (distinct devices) has been exercised by the builders on one GPU only
+ * (N = 1 through RCCL; N = 3 and 8 ranks sharing the GPU through the device-copy branch): on real
+ * multi-GPU nodes it is unverified. */
 typedef struct rt_multi rt_multi;
 int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out);
 void rt_multi_shutdown(rt_multi *m);
@@ -340,7 +351,11 @@ int rt_multi_render(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
  * time, 1.74 ms with four in flight on a third of the wave slots each, rt_multi_set_concurrency;
  * tools/multi_pipeline.py).  The frame travels through pinned staging memory of the library, so
  * that rt_multi_submit does not wait for it; rt_multi_wait copies it to the caller's pointers.
- * Frames do not depend on how many are in flight.  No counterpart in the reference. */
+ * Frames do not depend on how many are in flight.  The exchanges of all rt_multi of a process run in
+ * ONE order on every GPU, the order of the rt_multi_submit calls (each is enqueued behind an event
+ * recorded after the previous exchange on that GPU; submits are serialised by a mutex), so that two
+ * communicators' transfers can never be scheduled in opposite orders on two GPUs.  rt_stats.ms_total
+ * stays 0 (it is rt_render's host-side bracket).  No counterpart in the reference. */
 int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_out);
 int rt_multi_wait(rt_multi *m, rt_stats *stats);
 /* rt_set_concurrency on every GPU: with K rt_multi in flight, each launching 1/K of the wave slots

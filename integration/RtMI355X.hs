@@ -161,7 +161,9 @@ withScene fl lights k =
   where
     withArrayLen' xs f = withArray xs f
     withRecords :: Int -> [r] -> (Ptr () -> r -> IO ()) -> (Ptr () -> IO b) -> IO b
-    withRecords size rs pk f = allocaBytes (max 1 (size * length rs)) $ \p -> do
+    -- (C heap, not allocaBytes: a mesh's tables are megabytes, which do not belong in pinned
+    --  byte arrays on the Haskell heap; the library copies them during the call and keeps no pointer)
+    withRecords size rs pk f = bracket (mallocBytes (max 1 (size * length rs))) free $ \p -> do
       zipWithM_ (\i r -> pk (p `plusPtr` (size * i)) r) [0 ..] rs
       f p
     pokeNode p (FlatNode box l r) = do
@@ -231,10 +233,15 @@ renderGPU rng w = unsafePerformIO $
 renderMultiGPU :: Int -> PureMT -> World -> [Color]
 renderMultiGPU nGpus rng w = unsafePerformIO $
   alloca $ \pm -> do
-    rc <- c_m_init (fromIntegral nGpus) nullPtr pm
-    m0 <- peek pm
-    check "rt_multi_init" (if m0 == nullPtr then return "" else c_m_error m0 >>= peekCString) rc
-    bracket (return m0) c_m_shutdown $ \m -> do
+    poke pm nullPtr
+    -- rt_multi_init hands back a handle even when it fails (so that the error text can be read, and
+    -- because some ranks' contexts and streams may exist already): the bracket is entered BEFORE the
+    -- return code is looked at, so that a failed init is shut down like a successful one
+    bracket (do rc <- c_m_init (fromIntegral nGpus) nullPtr pm
+                m0 <- peek pm
+                return (rc, m0))
+            (\(_, m0) -> when (m0 /= nullPtr) (c_m_shutdown m0)) $ \(rc, m) -> do
+      check "rt_multi_init" (if m == nullPtr then return "" else c_m_error m >>= peekCString) rc
       let err = c_m_error m >>= peekCString
           (f6, nGrids, spp) = sampleTable rng w
           n = round (wImgWd w) * round (wImgHt w)

@@ -16,6 +16,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -84,6 +86,8 @@ struct rt_multi {
   uint8_t *d_gathered8 = nullptr, *d_rgb8 = nullptr;
   size_t cap_stride = 0, cap_pixels = 0;
   std::vector<hipEvent_t> done;          // rank r's tiles are in its buffer
+  std::vector<hipEvent_t> xchg;          // rank r's side of this rt_multi's newest exchange has been enqueued up to here
+  size_t n3_in_flight = 0;               // floats (bytes) of the frame in flight: what rt_multi_wait hands over
   bool have_cam = false, have_samples = false;
   bool in_flight = false;                // a frame has been submitted and not yet waited for
   // pinned staging for the frame on its way to the caller's (pageable) memory: a device-to-host
@@ -97,6 +101,17 @@ struct rt_multi {
 };
 
 namespace {
+
+// Exchanges of DIFFERENT rt_multi on the same GPUs (K of them keep K frames in flight) run on
+// different streams and communicators.  Nothing in RCCL orders two communicators' transfer kernels
+// on a device, so two devices could schedule them in opposite orders, each kernel waiting for a
+// peer that is queued behind the other one.  Every device therefore runs its exchanges in ONE
+// process-wide order, the order of the rt_multi_submit calls: an exchange is enqueued behind an
+// event recorded after the previous exchange on that device, whoever owned it, and the whole
+// enqueue section is serialised by a mutex (host threads driving different rt_multi).
+std::mutex g_exchange_mutex;
+struct LastExchange { hipEvent_t ev; const rt_multi *owner; };
+std::map<int, LastExchange> g_last_exchange;   // by device id
 
 int mfail(rt_multi *m, int code, const char *fmt, ...) {
   char buf[640];
@@ -200,6 +215,7 @@ int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out) {
   m->ctx.assign(n_gpus, nullptr);
   m->stream.assign(n_gpus, nullptr);
   m->done.assign(n_gpus, nullptr);
+  m->xchg.assign(n_gpus, nullptr);
   m->d_tiles.assign(n_gpus, nullptr);
   m->d_tiles8.assign(n_gpus, nullptr);
   *out = m;  // returned even on failure so that rt_multi_last_error can be read; rt_multi_shutdown frees it
@@ -214,13 +230,21 @@ int rt_multi_init(int32_t n_gpus, const int32_t *devices, rt_multi **out) {
     m->stream[r] = (hipStream_t)s;
     M_HIP(m, hipSetDevice(m->devices[r]));
     M_HIP(m, hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming));
+    M_HIP(m, hipEventCreateWithFlags(&m->xchg[r], hipEventDisableTiming));
   }
   // Ranks on distinct GPUs exchange through RCCL.  Ranks that SHARE a device (a rehearsal of the
   // N-rank data path on a smaller box; RCCL refuses duplicate devices) exchange with
   // device-to-device copies instead: same buffers, same layout, same ordering.
   m->use_rccl = distinct;
   if (m->use_rccl) {
-    if (!m->rccl.load(m->err)) return RT_ERR_DEVICE;
+    if (!m->rccl.load(m->err)) {
+      // a lone GPU has nobody to exchange with: without RCCL it simply assembles its own tiles
+      // (with RCCL it sends itself a few bytes so that the binding is exercised on a one-GPU box)
+      if (n_gpus > 1) return RT_ERR_DEVICE;
+      m->use_rccl = false;
+      m->err.clear();
+      return RT_OK;
+    }
     m->comm.assign(n_gpus, nullptr);
     M_NCCL(m, m->rccl.CommInitAll(m->comm.data(), n_gpus, m->devices.data()));
   }
@@ -234,6 +258,11 @@ void rt_multi_shutdown(rt_multi *m) {
       (void)hipSetDevice(m->devices[r]);
       (void)hipStreamSynchronize(m->stream[r]);
     }
+  {
+    std::lock_guard<std::mutex> lock(g_exchange_mutex);   // (the streams are idle: nobody waits for these events any more)
+    for (auto it = g_last_exchange.begin(); it != g_last_exchange.end();)
+      it = it->second.owner == m ? g_last_exchange.erase(it) : std::next(it);
+  }
   for (ncclComm_t c : m->comm)
     if (c) (void)m->rccl.CommDestroy(c);
   free_frame_buffers(m);
@@ -241,6 +270,7 @@ void rt_multi_shutdown(rt_multi *m) {
     if (!m->ctx[r]) continue;
     (void)hipSetDevice(m->devices[r]);
     if (m->done[r]) (void)hipEventDestroy(m->done[r]);
+    if (m->xchg[r]) (void)hipEventDestroy(m->xchg[r]);
     rt_shutdown(m->ctx[r]);
   }
   (void)hipGetLastError();  // leave no stale error behind for the process's next HIP call
@@ -249,8 +279,14 @@ void rt_multi_shutdown(rt_multi *m) {
 
 const char *rt_multi_last_error(rt_multi *m) { return m ? m->err.c_str() : "null rt_multi"; }
 
+// The inputs of a frame in flight are not to be changed under it: rt_multi_wait sizes its copies from
+// the camera, and new buffers would free the ones the frame is still using.
+#define M_IDLE(m, what)                                                                                   \
+  if ((m)->in_flight) return mfail((m), RT_ERR_STATE, what ": a frame is in flight (rt_multi_wait first)")
+
 int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene) {
   if (!m || !scene) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_upload_scene");
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_upload_scene(m->ctx[r], scene));  // replicated (KB..MB)
   return RT_OK;
 }
@@ -258,6 +294,7 @@ int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene) {
 int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
                    int32_t n_triangles) {
   if (!m) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_refit");
   for (int r = 0; r < m->n; ++r)
     M_CTX(m, r, rt_refit_async(m->ctx[r], spheres, n_spheres, triangles, n_triangles, nullptr));
   return RT_OK;
@@ -265,6 +302,7 @@ int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, con
 
 int rt_multi_set_camera(rt_multi *m, const rt_camera *cam) {
   if (!m || !cam) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_set_camera");
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_camera(m->ctx[r], cam));
   m->cam = *cam;
   m->have_cam = true;
@@ -273,12 +311,14 @@ int rt_multi_set_camera(rt_multi *m, const rt_camera *cam) {
 
 int rt_multi_set_concurrency(rt_multi *m, int32_t n) {
   if (!m) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_set_concurrency");
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_concurrency(m->ctx[r], n));
   return RT_OK;
 }
 
 int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t spp) {
   if (!m || !f6) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_set_samples");
   for (int r = 0; r < m->n; ++r) M_CTX(m, r, rt_set_samples(m->ctx[r], f6, n_grids, spp));
   m->have_samples = true;
   return RT_OK;
@@ -301,6 +341,15 @@ int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
   }
   // 2. the one exchange step: gather on rank 0
   if (m->use_rccl) {
+    std::lock_guard<std::mutex> lock(g_exchange_mutex);
+    // behind the previous exchange on each of the devices, whichever rt_multi enqueued it
+    for (int r = 0; r < m->n; ++r) {
+      auto it = g_last_exchange.find(m->devices[r]);
+      if (it != g_last_exchange.end() && it->second.owner != m) {
+        M_HIP(m, hipSetDevice(m->devices[r]));
+        M_HIP(m, hipStreamWaitEvent(m->stream[r], it->second.ev, 0));
+      }
+    }
     M_NCCL(m, m->rccl.GroupStart());
     // (a transfer that fails to enqueue must not leave the group open: close it, then report)
     ncclResult_t bad = ncclSuccess;
@@ -331,6 +380,11 @@ int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
     if (bad != ncclSuccess)
       return mfail(m, RT_ERR_DEVICE, "RCCL gather (send/recv): %s", m->rccl.GetErrorString(bad));
     M_NCCL(m, closed);
+    for (int r = 0; r < m->n; ++r) {
+      M_HIP(m, hipSetDevice(m->devices[r]));
+      M_HIP(m, hipEventRecord(m->xchg[r], m->stream[r]));
+      g_last_exchange[m->devices[r]] = LastExchange{m->xchg[r], m};
+    }
   } else {
     for (int r = 1; r < m->n; ++r) {
       M_HIP(m, hipSetDevice(m->devices[r]));
@@ -360,6 +414,7 @@ int rt_multi_submit(rt_multi *m, uint32_t flags, float *rgb_out, uint8_t *rgb8_o
   }
   m->out_rgb = rgb_out;
   m->out_rgb8 = rgb8_out;
+  m->n3_in_flight = n3;
   m->in_flight = true;
   return RT_OK;
 }
@@ -389,8 +444,9 @@ int rt_multi_wait(rt_multi *m, rt_stats *stats) {
     total.ms_kernel = std::max(total.ms_kernel, st.ms_kernel);
     total.ms_launch = std::max(total.ms_launch, st.ms_launch);
   }
-  // (rt_collect has waited for rank 0's stream: the frame is in the staging buffers)
-  const size_t n3 = (size_t)m->cam.img_w * m->cam.img_h * 3;
+  // (rt_collect has waited for rank 0's stream: the frame is in the staging buffers; ms_total,
+  //  the blocking single-GPU call's host-side bracket, stays 0 here)
+  const size_t n3 = m->n3_in_flight;
   if (m->out_rgb) std::memcpy(m->out_rgb, m->h_rgb, n3 * sizeof(float));
   if (m->out_rgb8) std::memcpy(m->out_rgb8, m->h_rgb8, n3);
   if (stats) *stats = total;
