@@ -53,6 +53,70 @@ def gather_tiles(mine: torch.Tensor, gathered: Optional[torch.Tensor], dst: int 
     return dist.gather(mine, glist, dst=dst, async_op=async_op)
 
 
+class _Gpu:
+    """The stream / event layer DistributedFrame is written against: torch.cuda on a GPU."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+
+    def wrap_stream(self, handle):          # a context's own hipStream_t
+        return torch.cuda.ExternalStream(handle, device=self.device)
+
+    def new_stream(self):
+        return torch.cuda.Stream(device=self.device)
+
+    def new_event(self):
+        return torch.cuda.Event()
+
+    def use(self, stream):                  # context manager: `stream` is current inside
+        return torch.cuda.stream(stream)
+
+    def synchronize(self) -> None:
+        torch.cuda.synchronize(self.device)
+
+
+class HostStreams:
+    """The same layer for a host-only rehearsal (tests/test_distributed_gloo.py drives
+    DistributedFrame.submit / finish over gloo with a stub renderer whose "kernels" run
+    synchronously): every operation completes when it is called, so streams and events are
+    placeholders -- what runs for real is the slot / work / event BOOKKEEPING and the collective."""
+
+    class _Stream:
+        cuda_stream = 0
+
+        def wait_event(self, ev) -> None:
+            pass
+
+    class _Event:
+        def record(self, stream=None) -> None:
+            pass
+
+    class _Use:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def __init__(self, device: torch.device = torch.device("cpu")):
+        self.device = device
+
+    def wrap_stream(self, handle):
+        return HostStreams._Stream()
+
+    def new_stream(self):
+        return HostStreams._Stream()
+
+    def new_event(self):
+        return HostStreams._Event()
+
+    def use(self, stream):
+        return HostStreams._Use()
+
+    def synchronize(self) -> None:
+        pass
+
+
 class DistributedFrame:
     """One rank's side of the tiled, gathered, pipelined frame render.
 
@@ -66,7 +130,7 @@ class DistributedFrame:
 
     def __init__(self, make_renderer, rank: int, nranks: int, device: torch.device, in_flight: int = 3,
                  force_collective: bool = False, share_gpu: str = "auto",
-                 rehearse_share: Optional[Tuple[int, int]] = None, tune_worlds=None):
+                 rehearse_share: Optional[Tuple[int, int]] = None, tune_worlds=None, streams=None):
         """rehearse_share=(r, n): timing rehearsal on one GPU of what rank r of an n-rank job
         computes (its tiles only, no collective, the frame buffers then hold compact tiles).
         tune_worlds: callable k -> World for jobs that upload a new scene per frame (animation);
@@ -79,6 +143,7 @@ class DistributedFrame:
         runtime maps the contexts' streams onto hardware queues.  "yes" forces (in_flight,
         1/in_flight), "no" (in_flight, whole GPU).  The choice never changes a pixel."""
         self.rank, self.nranks, self.device = rank, nranks, device
+        self.gpu = streams if streams is not None else _Gpu(device)   # (a HostStreams in the CPU rehearsal)
         self.depth = max(1, in_flight)
         self.renderers = [make_renderer() for _ in range(self.depth)]
         for r in self.renderers:
@@ -88,6 +153,17 @@ class DistributedFrame:
         for r in self.renderers:
             r.set_partition(*(rehearse_share if self.rehearsal else (rank, nranks)))
         self.mode = self._choose_mode(share_gpu)
+        if nranks > 1 and not self.rehearsal and dist.is_available() and dist.is_initialized():
+            # ONE mode for the job: rank 0's choice (each rank timed its own share; the shares are
+            # alike, but "within a per cent of each other" must not leave the ranks with different
+            # numbers of frames in flight)
+            t = torch.tensor(list(self.mode), dtype=torch.int64, device=device)
+            dist.broadcast(t, src=0)
+            depth, div = int(t[0].item()), int(t[1].item())
+            self.depth = max(1, min(depth, len(self.renderers)))
+            for r in self.renderers:
+                r.set_concurrency(div)
+            self.mode = (self.depth, div)
         self.r = self.renderers[0]
         til = self.r.tiling()
         self.tile_floats, self.stride = partition_layout(til.n_tiles, til.tile_w, til.tile_h, nranks)
@@ -101,7 +177,7 @@ class DistributedFrame:
         # torch only wraps it, so that events and the collective's stream can be ordered
         # against it.  (Two streams from torch's pool were measured to land on one hardware
         # queue: no overlap at all.)
-        self.streams = [torch.cuda.ExternalStream(r.stream, device=device) for r in self.renderers]
+        self.streams = [self.gpu.wrap_stream(r.stream) for r in self.renderers]
         self.k = 0
         # force_collective: run the gather/assemble path even with one rank (self-test on a
         # one-GPU box of exactly the code the 8-GPU job runs)
@@ -114,9 +190,9 @@ class DistributedFrame:
         self.gathered = [torch.zeros(nranks * self.stride, dtype=torch.float32, device=device)
                          for _ in range(self.depth)] if self.is_root else [None] * self.depth
         self.works = [None] * self.depth
-        self.asm_stream = torch.cuda.Stream(device=device)
+        self.asm_stream = self.gpu.new_stream()
         self.asm_done = [None] * self.depth
-        self.own_copied = [torch.cuda.Event() for _ in range(self.depth)]
+        self.own_copied = [self.gpu.new_event() for _ in range(self.depth)]
 
     def _choose_mode(self, share_gpu: str):
         """(frames in flight, grid divisor) -- local timing only, no collective."""
@@ -145,14 +221,14 @@ class DistributedFrame:
             times = []
             n_frames = 4 * self.depth
             for rep in range(4):                 # the first repetition warms up and is dropped
-                torch.cuda.synchronize(self.device)
+                self.gpu.synchronize()
                 t0 = time.perf_counter()
                 for k in range(n_frames):
                     j = k % depth
                     if self.tune_worlds is not None:
                         self.renderers[j].set_world(self.tune_worlds(k))
                     self.renderers[j].render_tiles_async(scratch[j].data_ptr(), 0, 0)
-                torch.cuda.synchronize(self.device)
+                self.gpu.synchronize()
                 times.append(time.perf_counter() - t0)
             t = min(times[1:])
             if os.environ.get("RT_TUNE_DEBUG"):
@@ -190,7 +266,7 @@ class DistributedFrame:
                 r.render_async(self.frames[slot].data_ptr(), 0, flags, rs.cuda_stream)
             self.k += 1
             return
-        with torch.cuda.stream(rs):
+        with self.gpu.use(rs):
             if self.works[slot] is not None:
                 self.works[slot].wait()          # mine[slot] is free once its gather is done
             if self.asm_done[slot] is not None:
@@ -212,12 +288,12 @@ class DistributedFrame:
                 # in flight, first use of a slot: 2 % of the frame still zero when assembled.)
                 self.own_copied[slot].record(rs)
         if self.is_root:
-            with torch.cuda.stream(self.asm_stream):
+            with self.gpu.use(self.asm_stream):
                 self.works[slot].wait()
                 self.asm_stream.wait_event(self.own_copied[slot])
                 r.assemble_async(self.gathered[slot].data_ptr(), self.nranks, self.stride,
                                  self.frames[slot].data_ptr(), self.asm_stream.cuda_stream)
-                ev = torch.cuda.Event()
+                ev = self.gpu.new_event()
                 ev.record(self.asm_stream)
                 self.asm_done[slot] = ev
         self.k += 1
@@ -228,7 +304,7 @@ class DistributedFrame:
             for w in self.works:
                 if w is not None:
                     w.wait()
-        torch.cuda.synchronize(self.device)
+        self.gpu.synchronize()
 
     def close(self) -> None:
         for r in self.renderers:

@@ -110,3 +110,113 @@ def test_partition_layout():
     assert d.partition_layout(10, 8, 8, 1) == (192, 1920)
     assert d.partition_layout(10, 8, 8, 3) == (192, 4 * 192)
     assert d.partition_layout(32400, 8, 8, 8) == (192, 4050 * 192)
+
+
+# ---- DistributedFrame itself with N > 1: slots, works, events, mode broadcast -------------------
+
+class _StubRenderer:
+    """What DistributedFrame asks of an rt.Renderer, computed on the host: a frame is a pattern
+    of (frame number, global tile, pixel in tile); "kernels" complete inside the call.  Only the
+    bookkeeping of DistributedFrame and the collective are real here."""
+    W, H, SPP = 72, 40, 4
+
+    def __init__(self, rt, counter):
+        from types import SimpleNamespace
+        self.rt = rt
+        self.world = SimpleNamespace(width=self.W, height=self.H)
+        self.stream = 0
+        self.rank, self.nranks = 0, 1
+        self.counter = counter          # frames rendered by ALL contexts of this rank, in submit order
+        self.concurrency = None
+        self.rendered = []
+
+    def set_timing(self, on): pass
+    def set_concurrency(self, n): self.concurrency = n
+    def close(self): pass
+
+    def set_partition(self, rank, nranks):
+        self.rank, self.nranks = rank, nranks
+
+    def tiling(self):
+        from types import SimpleNamespace
+        tiles, (tw, th, tx, ty) = self.rt.tiles_of_rank(self.W, self.H, self.SPP, self.rank, self.nranks)
+        return SimpleNamespace(tile_w=tw, tile_h=th, tiles_x=tx, tiles_y=ty, n_tiles=tx * ty, n_local_tiles=len(tiles))
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr))
+
+    @staticmethod
+    def pattern(frame_no, tile, tw, th):
+        px = np.arange(tw * th, dtype=np.float32).reshape(th, tw, 1)
+        return (np.float32(frame_no * 1000 + tile) + px / np.float32(4096.0)) * np.ones((1, 1, 3), np.float32)
+
+    def render_tiles_async(self, ptr, flags, stream):
+        til = self.tiling()
+        tiles, _ = self.rt.tiles_of_rank(self.W, self.H, self.SPP, self.rank, self.nranks)
+        out = self._view(ptr, til.n_local_tiles * til.tile_w * til.tile_h * 3).reshape(len(tiles), til.tile_h, til.tile_w, 3)
+        frame_no = self.counter[0]
+        self.counter[0] += 1
+        self.rendered.append(frame_no)
+        for l, t in enumerate(tiles):
+            out[l] = self.pattern(frame_no, t, til.tile_w, til.tile_h)
+
+    def assemble_async(self, gathered_ptr, nranks, stride, frame_ptr, stream):
+        til = self.tiling()
+        g = self._view(gathered_ptr, nranks * stride)
+        f = self._view(frame_ptr, self.W * self.H * 3)
+        f[:] = assemble_numpy(g, nranks, stride, self.W, self.H, til.tile_w, til.tile_h, til.tiles_x, til.tiles_y).reshape(-1)
+
+
+def _frame_worker(rank, nranks, port, result_path):
+    sys.path.insert(0, ROOT)
+    import rt_amd as rt
+    distributed = __import__("importlib").import_module("ray-tracer_amd.distributed")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=nranks)
+    try:
+        counter = [0]
+        dev = torch.device("cpu")
+        # share_gpu "auto": every rank times the modes on its own; rank 0's choice must become the job's
+        df = distributed.DistributedFrame(lambda: _StubRenderer(rt, counter), rank, nranks, dev, in_flight=3,
+                                          share_gpu="auto", streams=distributed.HostStreams(dev))
+        counter[0] = 0                                   # (the start-up timing rendered frames of its own)
+        modes = [None] * nranks
+        dist.all_gather_object(modes, tuple(df.mode))
+        ok = len(set(modes)) == 1 and all(r.concurrency == df.mode[1] for r in df.renderers)
+        n_frames = 7                                      # slots are reused: 7 frames over <= 3 slots
+        seen = []
+        for k in range(n_frames):
+            df.submit(0)
+            if k % 2 == 1:                                # finish in the middle of the sequence as well
+                df.finish()
+                if rank == 0:
+                    seen.append((k, df.frame.clone()))
+        df.finish()
+        if rank == 0:
+            seen.append((n_frames - 1, df.frame.clone()))
+            til = df.r.tiling()
+            for k, fr in seen:
+                want = np.zeros((_StubRenderer.H, _StubRenderer.W, 3), np.float32)
+                for t in range(til.n_tiles):
+                    x0, y0 = (t % til.tiles_x) * til.tile_w, (t // til.tiles_x) * til.tile_h
+                    blk = _StubRenderer.pattern(k, t, til.tile_w, til.tile_h)
+                    hh, ww = min(til.tile_h, _StubRenderer.H - y0), min(til.tile_w, _StubRenderer.W - x0)
+                    want[y0:y0 + hh, x0:x0 + ww] = blk[:hh, :ww]
+                ok = ok and np.array_equal(fr.numpy()[:want.size], want.reshape(-1))
+            np.save(result_path, np.array([float(ok), float(df.mode[0]), float(df.mode[1])]))
+        dist.barrier()
+        df.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_distributed_frame_pipeline_over_gloo(tmp_path, nranks):
+    """DistributedFrame.submit / finish with N > 1 ranks (gloo, host streams, a stub renderer): frame
+    k of the sequence must arrive whole on rank 0 from every rank's k-th render, through reused
+    slots, and all ranks must run rank 0's (frames in flight, grid fraction)."""
+    result = os.path.join(tmp_path, "ok.npy")
+    mp.spawn(_frame_worker, args=(nranks, _free_port(), result), nprocs=nranks, join=True)
+    ok, depth, div = np.load(result)
+    assert ok == 1.0, f"frames or modes differ (mode {int(depth)}, 1/{int(div)})"

@@ -89,6 +89,33 @@ def test_frames_in_flight_through_submit_and_wait(rt, devices):
             m.close()
 
 
+def test_inputs_are_locked_while_a_frame_is_in_flight(rt):
+    """rt_multi_wait sizes what it hands over from the frame that was submitted; scene, camera and
+    samples cannot be changed under a frame in flight (RT_ERR_STATE), and the frame that was in flight
+    arrives whole."""
+    big = make_world(rt, "bench1", 160, 120, 4)
+    small = make_world(rt, "bench5", 64, 48, 1)
+    g_big, g_small = rt.generate_grids(3, 170, big.camera.aa), rt.generate_grids(4, 74, small.camera.aa)
+    ref_big, ref_small = single(rt, big, g_big)[0], single(rt, small, g_small)[0]
+    m = rt.MultiRenderer([0, 0])
+    try:
+        m.set_world(big)
+        m.set_samples(g_big)
+        m.submit(0)
+        with pytest.raises(rt.RtError, match="in flight"):
+            m.set_world(small)
+        with pytest.raises(rt.RtError, match="in flight"):
+            m.set_samples(g_small)
+        rgb, _, _ = m.wait()
+        assert rgb.shape == ref_big.shape and np.array_equal(rgb.view(np.uint32), ref_big.view(np.uint32))
+        m.set_world(small)
+        m.set_samples(g_small)
+        rgb, _, _ = m.render(0)
+        assert np.array_equal(rgb.view(np.uint32), ref_small.view(np.uint32))
+    finally:
+        m.close()
+
+
 def test_multi_reports_errors(rt):
     with pytest.raises(rt.RtError, match="rt_init"):
         rt.MultiRenderer([0, 4711])                    # no such GPU
