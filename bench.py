@@ -64,7 +64,36 @@ WORKLOADS = {
 }
 
 
-def make_world(name: str, t: float = 0.0):
+LOADER = {}   # --from-obj: what the loader path took (seconds), reported in config
+
+
+def scene_through_obj_loader(scene_name: str):
+    """Config 3 "via HaObj" (BASELINE.json configs[2]): the generated mesh written as .obj/.mtl in
+    the HaObj dialect, read back by parseObj + convertMesh + fromMesh (src/HaObj.hs:63,
+    src/Convert.hs:15-39, restated in rth_scene_load_obj) and given to sahBVH -- instead of the
+    programmatic scene.  Same lights as the programmatic scene (bench6World's, moved with the mesh)."""
+    import tempfile
+    objfile = importlib.import_module("ray-tracer_amd.objfile")
+    src = rt.Scene.builtin(scene_name)
+    d = tempfile.mkdtemp(prefix="rt_obj_")
+    path = os.path.join(d, "station.obj")
+    t0 = time.perf_counter()
+    objfile.dump_obj(src, path)
+    t1 = time.perf_counter()
+    scene = rt.Scene.from_obj(path, lights=[src.view.lights[i] for i in range(src.view.n_lights)])
+    a, b = objfile.triangles_array(src.view), objfile.triangles_array(scene.view)
+    same = (len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in ("a", "b", "c", "n"))
+            and np.array_equal(src.nodes()["box"], scene.nodes()["box"]) and np.array_equal(src.leaf_refs(), scene.leaf_refs()))
+    LOADER.update({"obj_bytes": os.path.getsize(path), "triangles": int(scene.view.n_triangles),
+                   "write_obj_s": round(t1 - t0, 3), "parse_convert_s": round(scene.load_seconds, 3),
+                   "sahBVH_s": round(scene.build_seconds, 3), "same_triangles_and_tree_as_programmatic_scene": bool(same)})
+    for f in (path, path[:-4] + ".mtl"):
+        os.remove(f)
+    os.rmdir(d)
+    return scene
+
+
+def make_world(name: str, t: float = 0.0, from_obj: bool = False):
     scene_name, cfg_name, w, h, view, rpp, lens = WORKLOADS[name]
     if cfg_name is None:
         anim = importlib.import_module("ray-tracer_amd.animation")
@@ -79,7 +108,7 @@ def make_world(name: str, t: float = 0.0):
     cfg.anti_aliasing = rpp
     if lens is not None:
         cfg.lens = lens
-    scene = rt.Scene.builtin(scene_name)
+    scene = scene_through_obj_loader(scene_name) if from_obj else rt.Scene.builtin(scene_name)
     return rt.config_to_world(cfg, scene)
 
 
@@ -168,6 +197,9 @@ def main() -> None:
                     help="animation (c5): a context rebuilds sahBVH on the host and uploads only for every K-th of "
                          "its frames and refits the boxes on the GPU in between (rt_refit_async); 1 = rebuild "
                          "every frame, as the reference's host would")
+    ap.add_argument("--from-obj", action="store_true",
+                    help="mesh workloads (c3): the scene goes dump_obj -> Scene.from_obj (parseObj/convertMesh/fromMesh) -> "
+                         "sahBVH instead of the programmatic scene; loader and build seconds are reported in config")
     ap.add_argument("--rehearse-share", default=None, metavar="R/N",
                     help="one-GPU timing rehearsal of rank R's share of an N-rank job (no collective); "
                          "the line then reports that share's rays only")
@@ -189,7 +221,9 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
-    world = make_world(args.workload)
+    if args.from_obj and not WORKLOADS[args.workload][0].startswith("mesh:"):
+        raise SystemExit("--from-obj: only the mesh workloads have an .obj form (c3)")
+    world = make_world(args.workload, from_obj=args.from_obj)
     grids = rt.generate_grids(SEED, world.width + 10, world.camera.aa)
 
     def make_renderer():
@@ -282,6 +316,8 @@ def main() -> None:
         }
         if args.rehearse_share:
             out["config"]["rehearsal_of_rank_share"] = args.rehearse_share
+        if args.from_obj:
+            out["config"]["scene_via_obj_loader"] = dict(LOADER)
         if animated:
             out["config"]["bvh_per_frame"] = ("sahBVH rebuilt on the host + upload every frame" if args.rebuild_every <= 1 else
                                               f"rebuilt + uploaded every {args.rebuild_every} frames of a context, boxes refitted on the GPU in between")

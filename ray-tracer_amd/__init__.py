@@ -322,7 +322,9 @@ class Scene:
     def from_obj(cls, path: str, lights: Optional[Sequence[Light]] = None, bvh: str = "sah") -> "Scene":
         """parseObj + convertMesh + fromMesh (HaObj.hs:63, Convert.hs:15-39).  `lights`
         None = the eight point lights of bench6World (Main.hs:239-246)."""
+        import time
         err = C.create_string_buffer(512)
+        t0 = time.perf_counter()
         h = host_lib().rth_scene_load_obj(path.encode(), err, 512)
         if not h:
             raise RtError(f"cannot load {path}: {err.value.decode()}")
@@ -332,7 +334,10 @@ class Scene:
         else:
             for l in lights:
                 host_lib().rth_scene_add_light(s._h, C.byref(l))
+        t1 = time.perf_counter()
         s.build_bvh(bvh)
+        # (what bench.py --from-obj reports: parse + convert, then sahBVH)
+        s.load_seconds, s.build_seconds = t1 - t0, time.perf_counter() - t1
         return s
 
     def build_bvh(self, builder: str = "sah") -> None:

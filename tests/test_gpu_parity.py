@@ -378,8 +378,8 @@ def test_obj_loaded_scene_matches_oracle(rt, oracle, renderer, tmp_path):
     in rth_scene_load_obj), lit by bench6World's eight lights (Main.hs:237-246), sahBVH built,
     rendered on the GPU and compared with the oracle on the same loaded scene: both traversal
     policies, ids and ray counts identical, frames to the parity bar."""
-    import os
-    from test_obj_import import dump_obj
+    import importlib
+    dump_obj = importlib.import_module("ray-tracer_amd.objfile").dump_obj
     src = rt.Scene.builtin("mesh:3000")
     path = os.path.join(tmp_path, "station.obj")
     dump_obj(src, path)
@@ -401,6 +401,75 @@ def test_obj_loaded_scene_matches_oracle(rt, oracle, renderer, tmp_path):
                (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
         assert g_st.rays_refraction > 0 and g_st.rays_reflection > 0 and g_st.primary_hits > 192 * 108
         check_image(rt, g_rgb, o_rgb)
+
+
+def test_config3_through_the_obj_loader_at_full_size(rt, oracle, renderer, tmp_path):
+    """BASELINE.json configs[2] as worded -- ".obj mesh scene via HaObj + BVH" -- at the size bench.py
+    runs it (workload c3: 100 000-triangle station-style mesh, 1920x1080, 4 rays per pixel): the
+    mesh goes dump_obj -> rth_scene_load_obj (parseObj / convertMesh / fromMesh, HaObj.hs:63,
+    Convert.hs:15-39) -> sahBVH -> GPU.  The loaded scene has the programmatic scene's triangles,
+    normals and tree, its frame is BITWISE the programmatic scene's (which
+    test_full_size_frame_properties checks against the oracle), and stripes of it match the oracle
+    rendering the LOADED scene."""
+    import importlib
+    objfile = importlib.import_module("ray-tracer_amd.objfile")
+    W, H, rpp = 1920, 1080, 4
+    src = rt.Scene.builtin("mesh:100000")
+    path = os.path.join(tmp_path, "station.obj")
+    objfile.dump_obj(src, path)
+    scene = rt.Scene.from_obj(path, lights=[src.view.lights[i] for i in range(src.view.n_lights)])
+    a, b = objfile.triangles_array(src.view), objfile.triangles_array(scene.view)
+    assert len(a) == len(b) > 90000
+    for f in ("a", "b", "c", "n"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(src.nodes()["box"], scene.nodes()["box"]) and np.array_equal(src.leaf_refs(), scene.leaf_refs())
+    frames = []
+    for sc in (src, scene):
+        cfg = rt.default_config("mesh")
+        cfg.image_width, cfg.image_height, cfg.anti_aliasing = W, H, rpp
+        cfg.view_width, cfg.view_height, cfg.view_distance = 16, 9, 10
+        w = rt.config_to_world(cfg, sc)
+        grids = rt.generate_grids(77, W + 10, w.camera.aa)
+        renderer.set_partition(0, 1)
+        renderer.set_world(w)
+        renderer.set_samples(grids)
+        rgb, ids, st = renderer.render(0, want_hit_ids=True)
+        frames.append((rgb, ids, st, w, grids))
+    (p_rgb, p_ids, p_st, _, _), (l_rgb, l_ids, l_st, w, grids) = frames
+    assert np.array_equal(p_rgb.view(np.uint32), l_rgb.view(np.uint32))
+    assert np.array_equal(p_ids, l_ids) and p_st.rays_total == l_st.rays_total
+    for r0 in (H // 2 - 2, H - 4):
+        o_rgb, o_ids, _ = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT, rows=(r0, r0 + 4))
+        sl = slice(r0 * W, (r0 + 4) * W)
+        assert int((l_ids[sl] != o_ids[sl]).sum()) == 0
+        check_image(rt, l_rgb[sl], o_rgb[sl])
+
+
+def test_frame_from_the_seed_level_sample_table(rt, oracle, renderer):
+    """the sample table a GHC build of the reference would draw from a SEED
+    (generateGrids (pureMT seed), RayTracer.hs:462-481, with mersenne-random-pure64 / random /
+    random-shuffle restated in rth_generate_grids_pure64 -- PARITY UNPINNED: the packages are not in
+    the reference, only MT19937-64's published known answers pin the stream) fed to the kernel and
+    to the oracle: ids and ray counts identical, frame to the parity bar.  Its structure is the
+    reference's: aa^2 stratified cells per grid, lens and light samples permutations of the jitter."""
+    w = make_world(rt, "bench1", 160, 120, 16)
+    grids = rt.generate_grids_pure64(20240611, w.width + 10, w.camera.aa)
+    assert grids.shape == (w.width + 10, 16, 6) and float(grids.min()) >= 0.0 and float(grids.max()) <= 1.0
+    # (p, q) stratified: cell (c, r) of the aa x aa grid holds one sample; (r0, r1), (s0, s1) are permutations of them
+    g0 = grids[0]
+    cells = sorted((int(p * 4), int(q * 4)) for p, q in g0[:, :2])
+    assert cells == [(c, r) for c in range(4) for r in range(4)]
+    as_set = lambda a: sorted(map(tuple, np.asarray(a).tolist()))
+    assert as_set(g0[:, 2:4]) == as_set(g0[:, 0:2]) == as_set(g0[:, 4:6])
+    renderer.set_partition(0, 1)
+    renderer.set_world(w)
+    renderer.set_samples(grids)
+    g_rgb, g_ids, g_st = renderer.render(0, want_hit_ids=True)
+    o_rgb, o_ids, o_st = oracle.render(w, grids, oracle.FLAG_CULL_ZERO_WEIGHT)
+    assert int((g_ids != o_ids).sum()) == 0
+    assert (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+           (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+    check_image(rt, g_rgb, o_rgb)
 
 
 def test_leaving_the_medium_branch_and_infinite_weights(rt, oracle, renderer):

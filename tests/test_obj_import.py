@@ -121,43 +121,13 @@ def test_load_obj_errors(rt, tmp_path, obj, mtl, needle):
     assert needle in str(e.value)
 
 
-def fmt(x):
-    return np.format_float_positional(np.float32(x), unique=True, trim="0")
+import importlib
+import sys
 
-
-# the .mtl that build_mesh's materials correspond to (ray-tracer_amd/csrc/host/rt_host.cpp)
-MESH_MTL = {
-    0: ("hub", 3, (0.6, 0.6, 0.65), (1, 1, 1), 100, 1),
-    1: ("ring", 3, (1, 0.842, 0.1), (1, 0.842, 0.1), 50, 1),
-    2: ("pod", 6, (0, 0, 0), (1, 1, 1), 1000, 1.5),
-    3: ("pod2", 4, (0.2, 0.3, 0.9), (1, 1, 1), 100, 1.3),
-    4: ("spoke", 2, (0.9, 0.15, 0.1), (0.5, 0.5, 0.5), 10, 1),
-    5: ("floor_a", 2, (1, 1, 1), (0.5, 0.5, 0.5), 5, 1),
-    6: ("floor_b", 2, (0.15, 0.15, 0.2), (0.5, 0.5, 0.5), 5, 1),
-}
-
-
-def dump_obj(scene, path):
-    """Write a triangle scene in the HaObj dialect: one object, consecutive faces of one
-    material form one usemtl group."""
-    v = scene.view
-    with open(path[:-4] + ".mtl", "w") as f:
-        for name, illum, kd, ks, ns, ni in MESH_MTL.values():
-            f.write(f"newmtl {name}\nNs {fmt(ns)}\nKa 0 0 0\nKd {' '.join(map(fmt, kd))}\n"
-                    f"Ks {' '.join(map(fmt, ks))}\nNi {fmt(ni)}\nd 1\nillum {illum}\n\n")
-    with open(path, "w") as f:
-        f.write(f"# generated\nmtllib {os.path.basename(path)[:-4]}.mtl\no station\n")
-        for i in range(v.n_triangles):
-            t = v.triangles[i]
-            for p in (t.a, t.b, t.c):
-                f.write(f"v {fmt(p[0])} {fmt(p[1])} {fmt(p[2])}\n")
-        last = None
-        for i in range(v.n_triangles):
-            m = v.triangles[i].material
-            if m != last:
-                f.write(f"usemtl {MESH_MTL[m][0]}\ns off\n")
-                last = m
-            f.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_objfile = importlib.import_module("ray-tracer_amd.objfile")
+# the writer for the HaObj dialect lives beside the loader's Python side (bench.py --from-obj uses it too)
+fmt, MESH_MTL, dump_obj = _objfile.fmt, _objfile.MESH_MTL, _objfile.dump_obj
 
 
 def test_station_style_mesh_round_trips_through_obj(rt, oracle, tmp_path):
