@@ -132,11 +132,25 @@ def pmc_traffic(workload: str):
     vals = {}
     for line in open(path):
         f = line.split()
+        if len(f) >= 3 and f[0] == "#" and f[1] == "source_sha256":
+            vals["_source_sha256"] = f[2]
         if len(f) >= 3 and f[-1].startswith("avg="):
             vals[f[0]] = float(f[-1][4:])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, None, vals
     return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), vals
+
+
+def pmc_is_stale(pmc) -> bool:
+    """True when the committed counter pass was taken with other kernel / host sources than the ones
+    in this tree (tools/pmc_summary.py stamps every pass with their SHA-256; an unstamped pass
+    counts as stale): roofline.traffic and valu_issue then mix this run's times with old counters."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        return pmc.get("_source_sha256") != pmc_summary.source_sha256()
+    except Exception:
+        return True
 
 
 def cpu_baseline(world, grids, seconds_target: float = 25.0):
@@ -373,10 +387,11 @@ def main() -> None:
         r.render_async(df.frames[0].data_ptr(), 0, args.flags | rt.FLAG_TRACE_ZERO_WEIGHT | rt.FLAG_COUNT_TESTS, stream)
         out["config"]["rays_per_frame_reference_accounting"] = int(r.collect(stream).rays_total)
         traffic, traffic_src, pmc = pmc_traffic(args.workload)
+        pmc_stale = pmc_is_stale(pmc) if pmc else None
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(tf, 3), "peak": PEAK_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
-            "traffic_from_committed_pmc_pass": traffic_src,
+            "traffic_from_committed_pmc_pass": traffic_src, "pmc_stale": pmc_stale,
             "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_how": "HIP events around render_kernel on its launch stream, 1 frame in flight, "
                              f"mean of {args.steps} launches",
