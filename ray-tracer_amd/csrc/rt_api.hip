@@ -875,6 +875,8 @@ int launch(rt_ctx *c, uint32_t flags, float *d_out, int compact, uint32_t *d_ids
   if (!m.acc_known_clean && m.acc_pixels)
     HIP_TRY(c, hipMemsetAsync(m.acc, 0, m.acc_pixels * 3 * sizeof(long long), s));
   c->last_stats = m.stats;
+  if (STATS_TRACE_WORDS > 0)
+    HIP_TRY(c, hipMemsetAsync(m.stats + STATS_TRACE_BASE, 0, (size_t)STATS_TRACE_WORDS * sizeof(unsigned long long), s));
   if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
   (void)hipGetLastError();  // the check below is for THESE launches, not for a stale error of the process
   if (fma) launch_render_fma(p, cfg, s);
@@ -1379,7 +1381,7 @@ int rt_wave_diag(rt_ctx *c, uint64_t *out, int32_t max_waves) {
   if (!c || !out || max_waves < 1) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
-  int n = std::min<int>(max_waves, STATS_MAX_WAVES + STATS_DIAG_WORDS / 4);  // the last rows: sums of a profiling build
+  int n = std::min<int>(max_waves, STATS_MAX_WAVES + (STATS_DIAG_WORDS + STATS_TRACE_WORDS) / 4);  // the last rows: sums / step traces of diagnostic builds
   HIP_TRY(c, hipMemcpy(out, (c->last_stats ? c->last_stats : c->d_stats) + 16, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }

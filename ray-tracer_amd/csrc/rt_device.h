@@ -80,7 +80,16 @@ constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~
 // with record index < 64 << k (k = 0..6) and all
 constexpr int STATS_WAVE_BASE = 16, STATS_MAX_WAVES = 16384;
 constexpr int STATS_DIAG_BASE = STATS_WAVE_BASE + 4 * STATS_MAX_WAVES, STATS_DIAG_WORDS = 160;
-constexpr int STATS_WORDS = STATS_DIAG_BASE + STATS_DIAG_WORDS;
+// -DRT_TRACE_STEPS (tools/step_trace.py, never the shipped library): wall-clock stamps (100 MHz) of the
+// phase marks of the first STATS_TRACE_STEPS scheduling steps of the first STATS_TRACE_WAVES waves
+#ifdef RT_TRACE_STEPS
+constexpr int STATS_TRACE_WAVES = 64, STATS_TRACE_STEPS = 48, STATS_TRACE_MARKS = 12;
+#else
+constexpr int STATS_TRACE_WAVES = 0, STATS_TRACE_STEPS = 0, STATS_TRACE_MARKS = 12;
+#endif
+constexpr int STATS_TRACE_BASE = STATS_DIAG_BASE + STATS_DIAG_WORDS;
+constexpr int STATS_TRACE_WORDS = STATS_TRACE_WAVES * STATS_TRACE_STEPS * STATS_TRACE_MARKS;
+constexpr int STATS_WORDS = STATS_TRACE_BASE + STATS_TRACE_WORDS;
 
 struct RenderParams {
   const float4 *nodes;
