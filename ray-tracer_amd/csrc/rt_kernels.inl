@@ -914,15 +914,24 @@ constexpr unsigned SLOT_REFRACTION = 0x80000000u;
 #ifdef RT_PROFILE_PHASES
 #define PH_DECL unsigned long long ph_start = __builtin_amdgcn_s_memtime(), ph_t = ph_start, ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0, ph_lanes = 0
 #define PH_MARK(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_MARK_LIT PH_MARK(2)
+#elif defined(RT_TRACE_STEPS)
+// (time line of single steps: tools/step_trace.py)
+#define PH_DECL
+#define PH_MARK(i) do { if (gwave < (unsigned long long)STATS_TRACE_WAVES && n_steps <= (unsigned)STATS_TRACE_STEPS && lane == 0) \
+    P.stats[STATS_TRACE_BASE + ((size_t)gwave * STATS_TRACE_STEPS + (n_steps - 1)) * STATS_TRACE_MARKS + (i)] = wall_clock64(); } while (0)
+#define PH_MARK_LIT PH_MARK(10)
 #elif defined(RT_ASM_MARKS)
 // (static instruction counts per phase: markers in the assembly listing, tools/phase_static.py)
 #define PH_DECL
 #define PH_STR2(x) #x
 #define PH_STR(x) PH_STR2(x)
 #define PH_MARK(i) asm volatile("; PHASE_MARK " #i " line " PH_STR(__LINE__))
+#define PH_MARK_LIT PH_MARK(2)
 #else
 #define PH_DECL
 #define PH_MARK(i)
+#define PH_MARK_LIT
 #endif
 
 #ifndef RT_WAVES_PER_SIMD
@@ -1381,7 +1390,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       }
     }
 
-    PH_MARK(2);
+    PH_MARK_LIT;
     // ---- accumulate weight * direct colour into the PIXEL -----------------------------
     // Inside the chunk, lanes of one pixel are first summed with a segmented wave scan
     // over contiguous runs; the last lane of each run adds the run's sum to the pixel's
