@@ -196,6 +196,30 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
 int rt_refit_async(rt_ctx *ctx, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
                    int32_t n_triangles, void *hip_stream);
 
+/* Animation whose objects move so far (or change in number) that the old tree will not do: BUILD the
+ * tree on the GPU instead of handing one over (the reference's builder,
+ * src/BoundingVolumeHierarchy.hs:34-94, stays the host's for still scenes).  The objects are uploaded
+ * and a linear BVH is built over them on the context's stream: Morton order of the box centres,
+ * Karras' parallel radix tree, one object per leaf, boxes bottom-up with toBox / surround
+ * (BoundingVolumeHierarchy.hs:135-142,178-189), then the device records as rt_upload_scene would
+ * make them (100 000 triangles: about a millisecond, against 0.2 s for the host sahBVH and 9 ms for
+ * its upload).  Replaces rt_upload_scene for that frame; camera and samples are kept.
+ * This is a TREE-CHANGING mode: the tree is not sahBVH's, so (i) among hits at EQUAL distance the
+ * winner may differ from a frame rendered with the host's tree (the right subtree wins:
+ * src/RayTracer.hs:383-387,410), (ii) the reference's un-pruned visits differ.  The frame equals what
+ * the reference's algorithm returns when it walks THIS tree: rt_download_tree hands it back in
+ * rt_scene's format for exactly that check (the objects keep their positions in the two arrays:
+ * leaf_refs index them as in rt_upload_scene).  rt_refit_async does not work on such a tree (build
+ * again).  Blocking (two small read-backs); host arrays are copied before it returns.  Limit: 2^24
+ * objects, depth <= 64 (RT_ERR_LIMIT). */
+int rt_build_scene(rt_ctx *ctx, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                   int32_t n_triangles, const rt_material *materials, int32_t n_materials, const rt_light *lights,
+                   int32_t n_lights);
+/* The tree rt_build_scene made, as rt_upload_scene's input: 2 * n - 1 nodes (node 0 = the root; every
+ * leaf holds one object) and n leaf_refs.  nodes_out = leaf_refs_out = NULL: only the two counts. */
+int rt_download_tree(rt_ctx *ctx, rt_bvh_node *nodes_out, int32_t cap_nodes, uint32_t *leaf_refs_out, int32_t cap_refs,
+                     int32_t *n_nodes_out, int32_t *n_refs_out);
+
 /* The remaining World fields (src/Types.hs:132-141,143,145). */
 int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 
@@ -333,6 +357,9 @@ void rt_multi_shutdown(rt_multi *m);
 int rt_multi_upload_scene(rt_multi *m, const rt_scene *scene);
 int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
                    int32_t n_triangles);   /* rt_refit_async on every GPU */
+int rt_multi_build_scene(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                         int32_t n_triangles, const rt_material *materials, int32_t n_materials, const rt_light *lights,
+                         int32_t n_lights);   /* rt_build_scene on every GPU (the same tree on each) */
 int rt_multi_set_camera(rt_multi *m, const rt_camera *cam);
 int rt_multi_set_samples(rt_multi *m, const float *f6, int32_t n_grids, int32_t spp);
 /* render on all GPUs (blocking).  rgb_out: img_w*img_h*3 floats as rt_render, or NULL;

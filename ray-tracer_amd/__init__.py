@@ -117,6 +117,7 @@ DEVICE_SYMBOLS = [
     "rt_wave_diag", "rt_get_stream", "rt_set_concurrency", "rt_set_timing", "rt_render_static_async",
     "rt_assemble8_async", "rt_multi_init", "rt_multi_shutdown", "rt_multi_upload_scene", "rt_multi_set_camera",
     "rt_multi_set_samples", "rt_multi_render", "rt_multi_submit", "rt_multi_wait", "rt_multi_set_concurrency", "rt_multi_last_error", "rt_refit_async", "rt_multi_refit",
+    "rt_build_scene", "rt_download_tree", "rt_multi_build_scene",
 ]
 HOST_SYMBOLS = [
     "rth_scene_builtin", "rth_scene_create", "rth_scene_free", "rth_scene_load_obj",
@@ -238,11 +239,16 @@ def device_lib() -> C.CDLL:
         L.rt_multi_wait.argtypes = [vp, C.POINTER(Stats)]
         L.rt_multi_set_concurrency.argtypes = [vp, i32]
         L.rt_multi_refit.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32]
+        L.rt_multi_build_scene.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32, C.POINTER(Material), i32,
+                                           C.POINTER(Light), i32]
         L.rt_multi_last_error.argtypes = [vp]
         L.rt_multi_last_error.restype = C.c_char_p
         L.rt_collect.argtypes = [vp, vp, C.POINTER(Stats)]
         L.rt_quantize_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
         L.rt_wave_diag.argtypes = [vp, C.POINTER(u64), i32]
+        L.rt_build_scene.argtypes = [vp, C.POINTER(Sphere), i32, C.POINTER(Triangle), i32, C.POINTER(Material), i32,
+                                     C.POINTER(Light), i32]
+        L.rt_download_tree.argtypes = [vp, C.POINTER(BvhNode), i32, C.POINTER(u32), i32, C.POINTER(i32), C.POINTER(i32)]
         L.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.rt_set_concurrency.argtypes = [vp, i32]
         L.rt_set_timing.argtypes = [vp, i32]
@@ -504,6 +510,30 @@ class Renderer:
         self._check(self.lib.rt_set_camera(self._h, C.byref(world.camera)), "rt_set_camera")
         self.world = world
 
+    def build_world(self, world: World) -> None:
+        """rt_build_scene: the world's objects, materials and lights with a tree built ON THE GPU
+        (linear BVH) instead of the world's own (host sahBVH) tree; camera as set_world."""
+        v = world.scene.view
+        self._check(self.lib.rt_build_scene(self._h, v.spheres, v.n_spheres, v.triangles, v.n_triangles, v.materials,
+                                            v.n_materials, v.lights, v.n_lights), "rt_build_scene")
+        self._check(self.lib.rt_set_camera(self._h, C.byref(world.camera)), "rt_set_camera")
+        self.world = world
+
+    def download_tree(self) -> SceneView:
+        """The device-built tree as a SceneView over the current world's objects (rt_download_tree):
+        what rt_upload_scene -- or the oracle -- takes."""
+        nn, nr = i32(0), i32(0)
+        self._check(self.lib.rt_download_tree(self._h, None, 0, None, 0, C.byref(nn), C.byref(nr)), "rt_download_tree")
+        nodes = (BvhNode * max(1, nn.value))()
+        refs = (u32 * max(1, nr.value))()
+        self._check(self.lib.rt_download_tree(self._h, nodes, nn.value, refs, nr.value, C.byref(nn), C.byref(nr)),
+                    "rt_download_tree")
+        v = self.world.scene.view
+        out = SceneView(nodes, nn.value, refs, nr.value, v.spheres, v.n_spheres, v.triangles, v.n_triangles,
+                        v.materials, v.n_materials, v.lights, v.n_lights)
+        out._keep = (nodes, refs, v)
+        return out
+
     def refit(self, scene: "Scene") -> None:
         """rt_refit_async: the uploaded scene's objects moved to `scene`'s positions (same counts
         and order); boxes refitted on the GPU, the tree's topology kept."""
@@ -629,6 +659,14 @@ class MultiRenderer:
         g = np.ascontiguousarray(grids, np.float32)
         self._check(self.lib.rt_multi_set_samples(self._h, g.ctypes.data_as(C.POINTER(f32)), g.shape[0],
                                                   g.shape[1]), "rt_multi_set_samples")
+
+    def build_world(self, world: World) -> None:
+        """rt_multi_build_scene: the tree built on every GPU instead of uploaded."""
+        v = world.scene.view
+        self._check(self.lib.rt_multi_build_scene(self._h, v.spheres, v.n_spheres, v.triangles, v.n_triangles, v.materials,
+                                                  v.n_materials, v.lights, v.n_lights), "rt_multi_build_scene")
+        self._check(self.lib.rt_multi_set_camera(self._h, C.byref(world.camera)), "rt_multi_set_camera")
+        self.world = world
 
     def refit(self, scene: "Scene") -> None:
         v = scene.view

@@ -55,7 +55,7 @@ def build_device(force=False, defines=(), tag="", cflags=()):
     units = [
         ("rt_kernels_strict", ["-ffp-contract=off"], [kern]),
         ("rt_kernels_fma", ["-ffp-contract=fast"], [kern]),
-        ("rt_api", ["-ffp-contract=off"], []),
+        ("rt_api", ["-ffp-contract=off"], [os.path.join(CSRC, "rt_build.inl")]),
         ("rt_multi", ["-ffp-contract=off"], []),
     ]
     base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]

@@ -17,6 +17,19 @@
 
 using namespace rtdev;
 
+// work memory of rt_build_scene (rt_build.inl), kept between builds
+struct BuildBuffers {
+  float *box_in = nullptr, *leaf_box6 = nullptr, *node_box = nullptr;   // object boxes (input order), leaf boxes (sorted), internal nodes' boxes
+  unsigned long long *keys = nullptr;                                   // Morton keys, unsorted | sorted
+  int2 *child = nullptr;                                                // Karras tree: children of internal node i
+  int *ints = nullptr;                                                  // parents of internal nodes | of leaves | heights | arrival counters
+  int3 *queue = nullptr;                                                // the wide collapse's two level queues
+  void *scalars_mem = nullptr, *sort_tmp = nullptr;
+  rt_bvh_node *export_nodes = nullptr;
+  size_t cap_box_in = 0, cap_leaf_box6 = 0, cap_node_box = 0, cap_keys = 0, cap_child = 0, cap_ints = 0, cap_queue = 0,
+         cap_scalars = 0, cap_sort_tmp = 0, cap_export_nodes = 0;
+};
+
 struct rt_ctx {
   int device = 0;
   int n_cus = 0;
@@ -48,6 +61,9 @@ struct rt_ctx {
   std::vector<int> h_wide_src, h_level_nodes, h_level_start;
   int n_spheres = 0, n_triangles = 0;
   bool refit_ready = false;
+  bool device_built = false;   // the tree came from rt_build_scene: no refit tables (rebuild instead), rt_download_tree works
+  int device_built_n = 0;      // objects in that tree
+  BuildBuffers build;
   uint32_t *d_prim_src = nullptr;
   int *d_wide_src = nullptr, *d_level_nodes = nullptr;
   float *d_prim_box = nullptr;
@@ -992,6 +1008,10 @@ void rt_shutdown(rt_ctx *c) {
                   c->d_pclass, c->d_block_hist, c->d_order};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  void *build_bufs[] = {c->build.box_in, c->build.leaf_box6, c->build.node_box, c->build.keys, c->build.child, c->build.ints,
+                        c->build.queue, c->build.scalars_mem, c->build.sort_tmp, c->build.export_nodes};
+  for (void *b : build_bufs)
+    if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evk0) (void)hipEventDestroy(c->evk0);
@@ -1017,6 +1037,7 @@ int rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_scene = false;
   c->prepared = false;
+  c->device_built = false;
   Repack rp;
   rp.sc = sc;
   rp.seen.assign((size_t)sc->n_nodes, 0);
@@ -1190,6 +1211,8 @@ int rt_refit_async(rt_ctx *c, const rt_sphere *spheres, int32_t n_spheres, const
                    int32_t n_triangles, void *stream) {
   if (!c) return RT_ERR_INVALID;
   if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_upload_scene has not been called");
+  if (c->device_built)
+    return fail(c, RT_ERR_STATE, "rt_refit_async: the tree was built by rt_build_scene, which keeps no refit tables: build again");
   if (n_spheres != c->n_spheres || n_triangles != c->n_triangles)
     return fail(c, RT_ERR_INVALID, "rt_refit_async: %d spheres / %d triangles, the uploaded scene has %d / %d", n_spheres,
                 n_triangles, c->n_spheres, c->n_triangles);
@@ -1436,3 +1459,5 @@ int rt_render(rt_ctx *c, uint32_t flags, float *rgb_out, uint32_t *ids_out, rt_s
 }
 
 }  // extern "C"
+
+#include "rt_build.inl"

@@ -300,6 +300,17 @@ int rt_multi_refit(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, con
   return RT_OK;
 }
 
+int rt_multi_build_scene(rt_multi *m, const rt_sphere *spheres, int32_t n_spheres, const rt_triangle *triangles,
+                         int32_t n_triangles, const rt_material *materials, int32_t n_materials, const rt_light *lights,
+                         int32_t n_lights) {
+  if (!m) return RT_ERR_INVALID;
+  M_IDLE(m, "rt_multi_build_scene");
+  // every GPU builds the same tree from the same objects (the build is deterministic: sorted unique keys)
+  for (int r = 0; r < m->n; ++r)
+    M_CTX(m, r, rt_build_scene(m->ctx[r], spheres, n_spheres, triangles, n_triangles, materials, n_materials, lights, n_lights));
+  return RT_OK;
+}
+
 int rt_multi_set_camera(rt_multi *m, const rt_camera *cam) {
   if (!m || !cam) return RT_ERR_INVALID;
   M_IDLE(m, "rt_multi_set_camera");

@@ -116,6 +116,28 @@ def test_inputs_are_locked_while_a_frame_is_in_flight(rt):
         m.close()
 
 
+def test_multi_with_device_built_trees(rt):
+    """rt_multi_build_scene: every rank builds the tree on its GPU; the assembled frame is bitwise the
+    frame of one context that built the same tree."""
+    world = make_world(rt, "bench3", 200, 150, 4)
+    grids = rt.generate_grids(8, 210, world.camera.aa)
+    r = rt.Renderer(0)
+    try:
+        r.build_world(world)
+        r.set_samples(grids)
+        ref, _, ref_st = r.render(0)
+    finally:
+        r.close()
+    m = rt.MultiRenderer([0, 0, 0])
+    try:
+        m.build_world(world)
+        m.set_samples(grids)
+        rgb, _, st = m.render(0)
+        assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32)) and st.rays_total == ref_st.rays_total
+    finally:
+        m.close()
+
+
 def test_multi_reports_errors(rt):
     with pytest.raises(rt.RtError, match="rt_init"):
         rt.MultiRenderer([0, 4711])                    # no such GPU
