@@ -211,6 +211,9 @@ def main() -> None:
                     help="animation (c5): a context rebuilds sahBVH on the host and uploads only for every K-th of "
                          "its frames and refits the boxes on the GPU in between (rt_refit_async); 1 = rebuild "
                          "every frame, as the reference's host would")
+    ap.add_argument("--device-build", action="store_true",
+                    help="animation (c5): every frame's tree is built on the GPU (rt_build_scene, a linear BVH) instead of "
+                         "sahBVH on the host + upload; a tree-changing mode (ties may resolve differently)")
     ap.add_argument("--from-obj", action="store_true",
                     help="mesh workloads (c3): the scene goes dump_obj -> Scene.from_obj (parseObj/convertMesh/fromMesh) -> "
                          "sahBVH instead of the programmatic scene; loader and build seconds are reported in config")
@@ -276,7 +279,8 @@ def main() -> None:
             slot = df.k % df.depth
             n = per_context.get(slot, 0)
             per_context[slot] = n + 1
-            df.submit(args.flags, make_world(args.workload, float(k)), refit=(n % max(1, args.rebuild_every)) != 0)
+            df.submit(args.flags, make_world(args.workload, float(k)), refit=(n % max(1, args.rebuild_every)) != 0,
+                      device_build=args.device_build)
         else:
             df.submit(args.flags)
 
@@ -333,7 +337,9 @@ def main() -> None:
         if args.from_obj:
             out["config"]["scene_via_obj_loader"] = dict(LOADER)
         if animated:
-            out["config"]["bvh_per_frame"] = ("sahBVH rebuilt on the host + upload every frame" if args.rebuild_every <= 1 else
+            out["config"]["bvh_per_frame"] = ("linear BVH built on the GPU every frame (rt_build_scene; host sahBVH still runs in make_world, unused)"
+                                              if args.device_build else
+                                              "sahBVH rebuilt on the host + upload every frame" if args.rebuild_every <= 1 else
                                               f"rebuilt + uploaded every {args.rebuild_every} frames of a context, boxes refitted on the GPU in between")
         if by_frames:
             # a step = one frame on EVERY rank (world_size frames); per-GPU work is fixed as N grows

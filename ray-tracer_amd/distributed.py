@@ -247,15 +247,19 @@ class DistributedFrame:
         """The most recently submitted frame (valid after finish())."""
         return self.frames[(self.k - 1) % self.depth] if self.k else self.frames[0]
 
-    def submit(self, flags: int = 0, world=None, refit: bool = False) -> None:
+    def submit(self, flags: int = 0, world=None, refit: bool = False, device_build: bool = False) -> None:
         """Enqueue one frame; returns without waiting for the GPU.  `world` (animation): the
         frame's own World, uploaded to the frame's context first (rt_upload_scene frees the
         previous scene, which waits for that context's frame in flight); with `refit` the context
-        keeps its tree and only refits the boxes to the world's objects on the GPU (rt_refit_async)."""
+        keeps its tree and only refits the boxes to the world's objects on the GPU (rt_refit_async);
+        with `device_build` the world's own tree is ignored and one is built on the GPU (rt_build_scene:
+        a tree-changing mode, see include/rt_mi355x.h)."""
         slot = self.k % self.depth
         rs, r = self.streams[slot], self.renderers[slot]
         if world is not None:
-            if refit:
+            if device_build:
+                r.build_world(world)     # the tree built on the GPU from the world's objects (rt_build_scene)
+            elif refit:
                 r.refit(world.scene)
             else:
                 r.set_world(world)
