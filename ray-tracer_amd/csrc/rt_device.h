@@ -77,7 +77,7 @@ constexpr int PACKET_SHARDS = 16;  // packet counters, one 128-B line each (<= ~
 // four words per wave (rt_wave_diag), then STATS_DIAG_WORDS of a profiling build's sums: [0..11] phase
 // cycles, [12] steps, [13] active lanes, [16..23] traversal iterations / lane shares, [24..30] iteration and re-arm cycles, [32..71] deepest
 // stack per closest-hit traversal, [72..111] per shadow ray of the pool, [112..119] wide-node visits
-// with record index < 64 << k (k = 0..6) and all
+// with record index < 64 << k (k = 0..6) and all, [120..128] where the lanes are per loop iteration (Counters::where)
 constexpr int STATS_WAVE_BASE = 16, STATS_MAX_WAVES = 16384;
 constexpr int STATS_DIAG_BASE = STATS_WAVE_BASE + 4 * STATS_MAX_WAVES, STATS_DIAG_WORDS = 160;
 // -DRT_TRACE_STEPS (tools/step_trace.py, never the shipped library): wall-clock stamps (100 MHz) of the

@@ -68,6 +68,11 @@ struct Counters {
   // shader-clock cycles of the wave inside [0] node / [1] leaf iterations of closest-hit traversals, [2], [3] shadow;
   // [4] cycles inside the shadow-ray pool's re-arm blocks, [5] their number, [6] rays they handed out
   unsigned long long tcyc[7];
+  // where the lanes are, summed over the loop iterations (wave-uniform counts, kept by every lane):
+  // [0] iterations of the shadow-ray pool, lanes [1] at a node, [2] at a leaf, [3] idle with rays left in the
+  // pool (waiting for a re-arm), [4] idle with the pool handed out (the tail);
+  // [5] iterations of closest-hit traversals (scenes in memory), lanes [6] at a node, [7] at a leaf, [8] done
+  unsigned long long where[9];
 #endif
 };
 #ifdef RT_PROFILE_PHASES
@@ -649,6 +654,9 @@ DEVI void traverse(const RenderParams &P, const float4 *sc, unsigned *stack, int
       for (;;) {
         const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
         if ((at_node | at_leaf) == 0) break;
+#ifdef RT_PROFILE_PHASES
+        if (!ANY) { cn.where[5] += 1; cn.where[6] += at_node; cn.where[7] += at_leaf; cn.where[8] += 64 - at_node - at_leaf; }
+#endif
         IT_T0;
         if (at_node >= at_leaf) {
           if (cur >= 0) {
@@ -819,6 +827,10 @@ DEVI unsigned shadow_lights(const RenderParams &P, const float4 *sc, unsigned *s
     }
     const int at_node = __popcll(__ballot(cur >= 0)), at_leaf = __popcll(__ballot(cur < 0 && cur != STOP));
     if ((at_node | at_leaf) == 0) break;
+#ifdef RT_PROFILE_PHASES
+    cn.where[0] += 1; cn.where[1] += at_node; cn.where[2] += at_leaf;
+    cn.where[remaining > 0 ? 3 : 4] += 64 - at_node - at_leaf;
+#endif
     const bool all_safe = __ballot(cur != STOP && !safe) == 0ull;
     IT_T0;
     if (at_node >= at_leaf) {
@@ -1580,6 +1592,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
   for (int i = 0; i < 8; ++i) atomicAdd(&P.stats[STATS_DIAG_BASE + 112 + i], (unsigned long long)cn.topk[i]);
   if (lane == 0)
     for (int i = 0; i < 7; ++i) atomicAdd(&P.stats[STATS_DIAG_BASE + 24 + i], cn.tcyc[i]);
+  if (lane == 0)
+    for (int i = 0; i < 9; ++i) atomicAdd(&P.stats[STATS_DIAG_BASE + 120 + i], cn.where[i]);
 #endif
   if (lane == 0) {
     const unsigned long long wave_t0 = P.stats[16 + gwave * 4];

@@ -54,6 +54,13 @@ for wl in sys.argv[1:] or ["c2"]:
             lane_it, wave_it = ph[16 + i], ph[20 + i] / 2.0**20
             print(f"   {nm} iterations: {wave_it/max(1,ph[12]):.1f} per scheduling step, {lane_it/max(1,wave_it):.1f} lanes in each, "
                   f"{ph[24 + i]/max(1,wave_it):.0f} cycles of wave time each ({100*ph[24 + i]/tot:.1f}% of all wave cycles)")
+        wh = ph[120:129]
+        if wh[0] > 0:
+            print(f"   shadow-ray pool, lanes per loop iteration ({int(wh[0])} iterations): at a node {wh[1]/wh[0]:.1f}, at a leaf {wh[2]/wh[0]:.1f}, "
+                  f"idle waiting for a re-arm {wh[3]/wh[0]:.1f}, idle with the pool handed out (tail) {wh[4]/wh[0]:.1f}")
+        if wh[5] > 0:
+            print(f"   closest-hit traversal (scene in memory), lanes per loop iteration ({int(wh[5])} iterations): at a node {wh[6]/wh[5]:.1f}, "
+                  f"at a leaf {wh[7]/wh[5]:.1f}, finished or never active {wh[8]/wh[5]:.1f}")
         if ph[29] > 0:
             print(f"   shadow-ray pool re-arms: {ph[29]/max(1,ph[12]):.1f} per scheduling step, {ph[30]/ph[29]:.1f} rays handed out in each, "
                   f"{ph[28]/ph[29]:.0f} cycles of wave time each ({100*ph[28]/tot:.1f}% of all wave cycles)")
