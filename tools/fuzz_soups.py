@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Longer run of tests/test_gpu_parity.py's random-soup fuzz: seeds A..B-1, both ray policies, GPU
-against the oracle (hit ids, ray counts, 8-bit frame).  usage: python3 tools/fuzz_soups.py [A] [B]"""
+against the oracle (hit ids, ray counts, 8-bit frame).  usage: python3 tools/fuzz_soups.py [A] [B] [--device-build]
+--device-build: the scene's tree is built on the GPU (rt_build_scene) and the oracle walks the downloaded tree."""
 import importlib
 import os
 import sys
@@ -16,15 +17,28 @@ import test_gpu_parity as T  # noqa: E402
 
 
 def main():
-    a = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    b = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    device_build = "--device-build" in sys.argv
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    a = int(args[0]) if len(args) > 0 else 0
+    b = int(args[1]) if len(args) > 1 else 200
     oracle.lib()
     r = rt.Renderer(0)
     bad = 0
     for seed in range(a, b):
         w = T._random_soup(rt, seed)
         for gflags, oflags in ((0, oracle.FLAG_CULL_ZERO_WEIGHT), (rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0)):
-            (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = T.run_both(rt, oracle, r, w, seed, gflags, oflags)
+            if device_build:
+                from types import SimpleNamespace
+                grids = rt.generate_grids(seed, w.width + 10, w.camera.aa)
+                r.set_partition(0, 1)
+                r.build_world(w)
+                r.set_samples(grids)
+                g_rgb, g_ids, g_st = r.render(gflags, want_hit_ids=True)
+                tw = SimpleNamespace(scene=SimpleNamespace(view=r.download_tree()), camera=w.camera, width=w.width,
+                                     height=w.height, spp=w.spp)
+                o_rgb, o_ids, o_st = oracle.render(tw, grids, oflags)
+            else:
+                (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = T.run_both(rt, oracle, r, w, seed, gflags, oflags)
             ids = int((g_ids != o_ids).sum())
             counts = (g_st.rays_primary, g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
                      (o_st.rays_primary, o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
