@@ -715,9 +715,23 @@ DEVI void light_ray(const float *Lp, V3 pt, float s0, float s1, V3 &l_dir, float
 // x ** p of the Phong term (:104).  pow(x, 1) is x for every x (NaN, 0 and inf included), so a
 // wave whose lit lanes all carry exponent 1 (the matte materials of the shipped scenes) skips
 // the ~100-instruction powf expansion altogether; mixed waves select per lane.
+// Otherwise x ** p = 2 ** (p * log2 x) on the hardware's log2 / exp2 (v_log_f32, v_exp_f32: 1 ulp each)
+// instead of the ~100-instruction powf expansion.  x is max 0 (n . h) in [0, 1]; the error of the log,
+// 2^-23 |log2 x|, is multiplied by p, so the result is off by at most (p |log2 x|) 2^-23 ln 2 relative --
+// 1.2e-6 wherever x ** p >= 1e-4 (p |log2 x| <= 13.3), i.e. wherever the term can be seen at all; the
+// oracle's glibc powf and the device's own powf differ by the same order.  No hit decision depends on a
+// colour.  0 ** p = 0 (p > 0) and NaN ** p = NaN come out of the hardware ops; anything ** 0 = 1 is selected.
+#ifdef RT_LIBM_POW
+DEVI float pow_x_p(float x, float p) { return powf(x, p); }
+#else
+DEVI float pow_x_p(float x, float p) {
+  const float w = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+  return p == 0.0f ? 1.0f : w;
+}
+#endif
 DEVI float phong_pow(float x, float p) {
   if (__ballot(p != 1.0f) == 0ull) return x;
-  const float w = powf(x, p);
+  const float w = pow_x_p(x, p);
   return p == 1.0f ? x : w;
 }
 
