@@ -713,14 +713,17 @@ DEVI void light_ray(const float *Lp, V3 pt, float s0, float s1, V3 &l_dir, float
 }
 
 // x ** p of the Phong term (:104).  pow(x, 1) is x for every x (NaN, 0 and inf included), so a
-// wave whose lit lanes all carry exponent 1 (the matte materials of the shipped scenes) skips
-// the ~100-instruction powf expansion altogether; mixed waves select per lane.
-// Otherwise x ** p = 2 ** (p * log2 x) on the hardware's log2 / exp2 (v_log_f32, v_exp_f32: 1 ulp each)
-// instead of the ~100-instruction powf expansion.  x is max 0 (n . h) in [0, 1]; the error of the log,
-// 2^-23 |log2 x|, is multiplied by p, so the result is off by at most (p |log2 x|) 2^-23 ln 2 relative --
-// 1.2e-6 wherever x ** p >= 1e-4 (p |log2 x| <= 13.3), i.e. wherever the term can be seen at all; the
-// oracle's glibc powf and the device's own powf differ by the same order.  No hit decision depends on a
-// colour.  0 ** p = 0 (p > 0) and NaN ** p = NaN come out of the hardware ops; anything ** 0 = 1 is selected.
+// wave whose lit lanes all carry exponent 1 (the matte materials of the shipped scenes) does no
+// power at all; mixed waves select per lane.
+// Otherwise x ** p = 2 ** (p * log2 x) on the hardware's log2 / exp2 (v_log_f32, v_exp_f32: 1 ulp
+// each), 3 instructions instead of the ~100 of the powf expansion.  x is max 0 (n . h) in [0, 1];
+// the error of the log, 2^-23 |log2 x|, is multiplied by p, so the result is off by about
+// (p |log2 x|) 2^-23 ln 2 relative: measured against double-precision pow for p = 0.5 .. 1e5
+// (tools/micro/pow_probe.hip, profiles/r03_pow_probe.txt) at most 1.4e-6 relative wherever
+// x ** p >= 1e-4 and 8.5e-8 absolute everywhere (the device's powf: 1.4e-7; the oracle's is
+// glibc's).  A colour only: no hit decision and no ray count depends on it.  0 ** p = 0 (p > 0)
+// and NaN ** p = NaN come out of the hardware ops; anything ** 0 = 1 is selected.
+// -DRT_LIBM_POW keeps powf.
 #ifdef RT_LIBM_POW
 DEVI float pow_x_p(float x, float p) { return powf(x, p); }
 #else
