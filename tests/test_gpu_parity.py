@@ -1017,6 +1017,52 @@ def _random_soup(rt, seed):
     return rt.config_to_world(cfg, sc)
 
 
+def test_phong_exponents_of_every_kind(rt, oracle, renderer):
+    """The Phong power is 2 ** (p * log2 x) on the hardware's log2 / exp2 (rt_kernels.inl pow_x_p); the oracle
+    calls glibc powf (RayTracer.hs:104).  Spheres with exponents the named materials do not have -- fractional,
+    1, small integers, 1e5 and 1e9 (p * log2 x overflows to -inf: 0) -- lit by two lights, every sphere
+    reflecting a little so that the term is also weighted into bounces: ids and ray counts equal, float frame
+    within the strict test's tolerance, under both ray policies.  Exponent 0 (anything ** 0 = 1) only under the
+    default policy and without reflection: its reflection jitter 1 / phong is infinite and the reflected ray
+    NaN, in the reference as well, and the reference's policy traces that ray whatever its weight."""
+    def world_with(exps):
+        mats = []
+        for k, p in enumerate(exps):
+            m = rt.material("whiteShiny")
+            m.phong = p
+            m.refl = 0.2 if p > 0 else 0.0
+            m.diffuse[:] = [(0.2, 0.3, 0.9), (0.9, 0.3, 0.2), (0.3, 0.9, 0.2)][k % 3]
+            mats.append(m)
+        floor_m = rt.material("whiteDull")
+        floor_m.phong = 25.0
+        mats.append(floor_m)
+        spheres = [rt.Sphere((f32 * 3)(-5.25 + 1.5 * k, 0.6, 0.3 * (k % 2)), 0.6, k, k) for k in range(len(exps))]
+        tris = [rt.make_triangle((-20, 0, -20), (-20, 0, 20), (20, 0, 20), len(exps)),
+                rt.make_triangle((-20, 0, -20), (20, 0, 20), (20, 0, -20), len(exps))]
+        for k, t in enumerate(tris):
+            t.object_id = len(spheres) + k
+        order = list(range(len(spheres))) + [rt.REF_TRIANGLE | k for k in range(len(tris))]
+        lights = [rt.Light((f32 * 3)(-3, 6, 4), (f32 * 3)(0.5, 0, 0), (f32 * 3)(0, 0, 0.5), (f32 * 3)(0.7, 0.7, 0.7)),
+                  rt.Light((f32 * 3)(4, 3, 5), (f32 * 3)(0.3, 0, 0), (f32 * 3)(0, 0.3, 0), (f32 * 3)(0.4, 0.4, 0.5))]
+        sc = rt.Scene.create(spheres, tris, order, mats, lights, bvh="sah")
+        cfg = rt.Config(image_width=240, image_height=90, view_width=16, view_height=6, view_distance=7,
+                        reflection_depth=3, anti_aliasing=4, eye=(0.0, 2.0, 9.0), look_at=(0.0, 0.5, 0.0), lens=0.0)
+        return rt.config_to_world(cfg, sc)
+
+    both = ((rt.FLAG_NO_PRUNE | rt.FLAG_TRACE_ZERO_WEIGHT, 0), (0, oracle.FLAG_CULL_ZERO_WEIGHT))
+    for exps, policies in (([0.25, 0.5, 1.0, 2.0, 3.7, 64.0, 1e5, 1e9], both), ([0.0, 0.5, 1.0, 2.0, 3.7, 64.0, 1e5, 1e9], both[1:])):
+        w = world_with(exps)
+        for gflags, oflags in policies:
+            (g_rgb, g_ids, g_st), (o_rgb, o_ids, o_st) = run_both(rt, oracle, renderer, w, 21, gflags, oflags)
+            assert o_st.nan_hits == 0 and np.isfinite(o_rgb).all()
+            assert int((g_ids != o_ids).sum()) == 0
+            assert (g_st.rays_shadow, g_st.rays_reflection, g_st.rays_refraction) == \
+                   (o_st.rays_shadow, o_st.rays_reflection, o_st.rays_refraction)
+            assert g_st.primary_hits > 240 * 90 * 4 // 3          # the spheres and the floor are in view
+            check_image(rt, g_rgb, o_rgb)
+            assert np.allclose(g_rgb, o_rgb, rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_soups_match_oracle(rt, oracle, renderer, seed):
     """Fuzz: scenes nobody designed (`_random_soup`), both ray policies.  Hit ids and ray counts
