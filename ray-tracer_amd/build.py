@@ -58,7 +58,11 @@ def build_device(force=False, defines=(), tag="", cflags=()):
         ("rt_api", ["-ffp-contract=off"], [os.path.join(CSRC, "rt_build.inl")]),
         ("rt_multi", ["-ffp-contract=off"], []),
     ]
-    base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
+    # -fno-slp-vectorize: left to itself the SLP vectoriser pairs the kernels' scalar float operations into
+    # v_pk_mul_f32 / v_pk_add_f32 (IEEE per element, so the same numbers), whose operands must sit in aligned
+    # register pairs: the copies and the pressure cost more than the packed issue saves -- 128 -> 118-125
+    # VGPRs, 14 -> 8 spilled in the five-wave kernel, c2 1.60 -> 1.50 ms per frame.
+    base = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
     base += ["-D" + d for d in defines] + list(cflags)
     objs = []
     relink = force

@@ -4,7 +4,7 @@
 Loops are counted once; the traversal phases are loop bodies (dynamic counts: tile_diag.py)."""
 import re, subprocess, sys, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "render_kernelILb1ELb0ELb1ELb0ELi4ELi5E"
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Iinclude", "-Iray-tracer_amd/csrc",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-Iinclude", "-Iray-tracer_amd/csrc",
        "-ffp-contract=off", "-DRT_ASM_MARKS", "-S", "--cuda-device-only", "ray-tracer_amd/csrc/rt_kernels_strict.hip", "-o", "/tmp/marks.s"]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 names = {0: "obtain rays (pop / decode)", 1: "closest traversal", 2: "shade (direct)", 3: "shadow traversal", 4: "accumulate",

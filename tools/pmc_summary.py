@@ -16,7 +16,9 @@ def source_sha256():
     """What the counters belong to: SHA-256 over the kernel and host sources of the library
     (bench.py puts "pmc_stale": true in its line when the tree's sources differ from this stamp)."""
     h = hashlib.sha256()
-    for f in ("ray-tracer_amd/csrc/rt_kernels.inl", "ray-tracer_amd/csrc/rt_api.hip", "ray-tracer_amd/csrc/rt_device.h"):
+    # (build.py: the compiler flags belong to what was measured)
+    for f in ("ray-tracer_amd/csrc/rt_kernels.inl", "ray-tracer_amd/csrc/rt_api.hip", "ray-tracer_amd/csrc/rt_device.h",
+              "ray-tracer_amd/build.py"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()
 
@@ -34,7 +36,7 @@ def main():
                 if pat in k and not counting:
                     acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     if acc:
-        print(f"# source_sha256 {source_sha256()}  (rt_kernels.inl + rt_api.hip + rt_device.h at the time of the passes)")
+        print(f"# source_sha256 {source_sha256()}  (rt_kernels.inl + rt_api.hip + rt_device.h + build.py at the time of the passes)")
     for name in sorted(acc):
         v = acc[name]
         print(f"{name:40s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
