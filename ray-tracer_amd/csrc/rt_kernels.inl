@@ -1393,8 +1393,13 @@ __global__ __launch_bounds__(64 * WPB, WPS) void render_kernel(const RenderParam
       }
     } else
     for (int li = P.n_lights - 1; li >= 0; --li) {
-      // (this build is chosen for scenes with at most one light: light 0 has a copy in LDS)
-      const float *Lp = li == 0 ? hotL + 32 : P.lights + (size_t)li * 12;
+      // Light 0 has a copy in LDS.  The pruned, uncounted instances of this build only ever run with at
+      // most one light (with_render_kernel: several lights take the MLIGHT instances), and for them the
+      // pointer must be the LDS one and nothing else: a select between it and P.lights makes every load
+      // of the light a FLAT load, whose s_waitcnt vmcnt(0) then waits, twice per step, for the
+      // acknowledgement of every queue store and pixel atomic the wave has in flight.  The counting and
+      // the reference-visit instances do run this loop with several lights.
+      const float *Lp = (PRUNE && !COUNT) ? hotL + 32 : (li == 0 ? hotL + 32 : P.lights + (size_t)li * 12);
       V3 l_dir;
       float max_d;
       light_ray(Lp, pt, s0, s1, l_dir, max_d);
