@@ -14,7 +14,7 @@ Use: in src/Main.hs replace `let img = render rng w` (Main.hs:44) by `let img = 
 (or `renderMultiGPU n rng w`), add this module to the cabal file with
 `extra-libraries: rt_mi355x` and `extra-lib-dirs:` pointing at ray-tracer_amd/lib.
 -}
-module RtMI355X (renderGPU, renderMultiGPU, flatten, Flat(..)) where
+module RtMI355X (renderGPU, renderGPUDeviceTree, renderMultiGPU, flatten, flattenObjects, Flat(..)) where
 
 import Control.Exception (bracket)
 import Control.Monad (when, zipWithM_)
@@ -38,6 +38,7 @@ data RtMulti   -- opaque rt_multi
 foreign import ccall safe   "rt_init"               c_rt_init    :: CInt -> Ptr (Ptr RtCtx) -> IO CInt
 foreign import ccall safe   "rt_shutdown"           c_rt_shutdown :: Ptr RtCtx -> IO ()
 foreign import ccall safe   "rt_upload_scene"       c_rt_upload  :: Ptr RtCtx -> Ptr () -> IO CInt
+foreign import ccall safe   "rt_build_scene"        c_rt_build   :: Ptr RtCtx -> Ptr () -> Int32 -> Ptr () -> Int32 -> Ptr () -> Int32 -> Ptr () -> Int32 -> IO CInt
 foreign import ccall safe   "rt_set_camera"         c_rt_camera  :: Ptr RtCtx -> Ptr () -> IO CInt
 foreign import ccall safe   "rt_set_samples"        c_rt_samples :: Ptr RtCtx -> Ptr CFloat -> Int32 -> Int32 -> IO CInt
 foreign import ccall safe   "rt_render"             c_rt_render  :: Ptr RtCtx -> Word32 -> Ptr CFloat -> Ptr Word32 -> Ptr () -> IO CInt
@@ -105,20 +106,31 @@ flatten bvh0  = finish (go bvh0 start)
     -- position (length - 1 - i)
     replaceFromEnd i x xs = let k = length xs - 1 - i in take k xs ++ [x] ++ drop (k + 1) xs
 
-    addObject st (Sphere c r m) =
-      let (mi, st') = materialIndex m st
-          ref = fromIntegral (length (stSph st')) :: Word32
-      in st' { stRefs = ref : stRefs st'
-             , stSph = (c, r, mi, stObj st') : stSph st', stObj = stObj st' + 1 }
-    addObject st (Triangle a b c n m) =
-      let (mi, st') = materialIndex m st
-          ref = 0x80000000 .|. fromIntegral (length (stTri st')) :: Word32
-      in st' { stRefs = ref : stRefs st'
-             , stTri = (a, b, c, n, mi, stObj st') : stTri st', stObj = stObj st' + 1 }
+-- | One more object: its record, its reference in list order, its material's index in the
+-- de-duplicated table.
+addObject :: St -> Object -> St
+addObject st (Sphere c r m) =
+  let (mi, st') = materialIndex m st
+      ref = fromIntegral (length (stSph st')) :: Word32
+  in st' { stRefs = ref : stRefs st'
+         , stSph = (c, r, mi, stObj st') : stSph st', stObj = stObj st' + 1 }
+addObject st (Triangle a b c n m) =
+  let (mi, st') = materialIndex m st
+      ref = 0x80000000 .|. fromIntegral (length (stTri st')) :: Word32
+  in st' { stRefs = ref : stRefs st'
+         , stTri = (a, b, c, n, mi, stObj st') : stTri st', stObj = stObj st' + 1 }
 
-    materialIndex m st = case elemIndex m (reverse (stMats st)) of
-      Just i  -> (fromIntegral i, st)
-      Nothing -> (fromIntegral (length (stMats st)), st { stMats = m : stMats st })
+materialIndex :: Material -> St -> (Int32, St)
+materialIndex m st = case elemIndex m (reverse (stMats st)) of
+  Just i  -> (fromIntegral i, st)
+  Nothing -> (fromIntegral (length (stMats st)), st { stMats = m : stMats st })
+
+-- | The objects alone, in list order and without a tree (`fNodes` empty): the input of rt_build_scene, which
+-- builds its own tree on the GPU.
+flattenObjects :: [Object] -> Flat
+flattenObjects objs =
+  let st = foldl addObject (St 0 [] [] [] [] [] 0) objs
+  in Flat [] (reverse (stRefs st)) (reverse (stSph st)) (reverse (stTri st)) (reverse (stMats st))
 
 data St = St { stN :: !Int, stNodes :: [FlatNode], stRefs :: [Word32]
              , stSph :: [(Vec3, Float, Int32, Int32)], stTri :: [(Vec3, Vec3, Vec3, Vec3, Int32, Int32)]
@@ -160,24 +172,34 @@ withScene fl lights k =
     k sc
   where
     withArrayLen' xs f = withArray xs f
-    withRecords :: Int -> [r] -> (Ptr () -> r -> IO ()) -> (Ptr () -> IO b) -> IO b
-    -- (C heap, not allocaBytes: a mesh's tables are megabytes, which do not belong in pinned
-    --  byte arrays on the Haskell heap; the library copies them during the call and keeps no pointer)
-    withRecords size rs pk f = bracket (mallocBytes (max 1 (size * length rs))) free $ \p -> do
-      zipWithM_ (\i r -> pk (p `plusPtr` (size * i)) r) [0 ..] rs
-      f p
     pokeNode p (FlatNode box l r) = do
       case box of
         Box x0 x1 y0 y1 z0 z1 -> zipWithM_ (\i v -> pokeF p (4 * i) v) [0 ..] [x0, x1, y0, y1, z0, z1]
         EmptyBox -> error "RtMI355X: EmptyBox in a built BVH"   -- hitsBox errors on it too (BVH.hs:192)
       pokeI p 24 l >> pokeI p 28 r
-    pokeSphere p (c, r, mi, oid) = pokeV3 p 0 c >> pokeF p 12 r >> pokeI p 16 mi >> pokeI p 20 oid
-    pokeTriangle p (a, b, c, n, mi, oid) =
-      pokeV3 p 0 a >> pokeV3 p 12 b >> pokeV3 p 24 c >> pokeV3 p 36 n >> pokeI p 48 mi >> pokeI p 52 oid
-    -- matAtten already holds the LOG of the attenuation colour (makeMaterial, Surfaces.hs:22-24)
-    pokeMaterial p (Material d s ph rl ri at) =
-      pokeC3 p 0 d >> pokeC3 p 12 s >> pokeF p 24 ph >> pokeF p 28 rl >> pokeF p 32 ri >> pokeC3 p 36 at
-    pokeLight p (Light c a b col) = pokeV3 p 0 c >> pokeV3 p 12 a >> pokeV3 p 24 b >> pokeC3 p 36 col
+
+-- | A table of fixed-size C records for the duration of a call.
+-- (C heap, not allocaBytes: a mesh's tables are megabytes, which do not belong in pinned
+--  byte arrays on the Haskell heap; the library copies them during the call and keeps no pointer)
+withRecords :: Int -> [r] -> (Ptr () -> r -> IO ()) -> (Ptr () -> IO b) -> IO b
+withRecords size rs pk f = bracket (mallocBytes (max 1 (size * length rs))) free $ \p -> do
+  zipWithM_ (\i r -> pk (p `plusPtr` (size * i)) r) [0 ..] rs
+  f p
+
+pokeSphere :: Ptr () -> (Vec3, Float, Int32, Int32) -> IO ()
+pokeSphere p (c, r, mi, oid) = pokeV3 p 0 c >> pokeF p 12 r >> pokeI p 16 mi >> pokeI p 20 oid
+
+pokeTriangle :: Ptr () -> (Vec3, Vec3, Vec3, Vec3, Int32, Int32) -> IO ()
+pokeTriangle p (a, b, c, n, mi, oid) =
+  pokeV3 p 0 a >> pokeV3 p 12 b >> pokeV3 p 24 c >> pokeV3 p 36 n >> pokeI p 48 mi >> pokeI p 52 oid
+
+-- matAtten already holds the LOG of the attenuation colour (makeMaterial, Surfaces.hs:22-24)
+pokeMaterial :: Ptr () -> Material -> IO ()
+pokeMaterial p (Material d s ph rl ri at) =
+  pokeC3 p 0 d >> pokeC3 p 12 s >> pokeF p 24 ph >> pokeF p 28 rl >> pokeF p 32 ri >> pokeC3 p 36 at
+
+pokeLight :: Ptr () -> Light -> IO ()
+pokeLight p (Light c a b col) = pokeV3 p 0 c >> pokeV3 p 12 a >> pokeV3 p 24 b >> pokeC3 p 36 col
 
 -- | rt_camera (104 bytes): the scalar fields of `World` (Types.hs:132-146).
 withCamera :: World -> (Ptr () -> IO a) -> IO a
@@ -228,6 +250,34 @@ renderGPU rng w = unsafePerformIO $
         check "rt_render" err =<< c_rt_render ctx 0 out nullPtr nullPtr
         toColors n out
 {-# NOINLINE renderGPU #-}
+
+-- | `render` with the tree built ON THE GPU (rt_build_scene: a linear BVH, one object per leaf) from the
+-- objects alone -- for a frame of an animation whose objects moved too far for last frame's tree and for which
+-- `sahBVH` on the host would cost more than the frame (100 000 triangles: 0.2 s against 2 ms).  `wObjects` of
+-- the world is not looked at.  A TREE-CHANGING mode: hits that tie in distance may be won by another object than
+-- under the `sahBVH` tree (include/rt_mi355x.h).
+renderGPUDeviceTree :: PureMT -> World -> [Object] -> [Color]
+renderGPUDeviceTree rng w objs = unsafePerformIO $
+  alloca $ \pctx -> do
+    check "rt_init" (return "no GPU?") =<< c_rt_init 0 pctx
+    bracket (peek pctx) c_rt_shutdown $ \ctx -> do
+      let err = c_rt_error ctx >>= peekCString
+          (f6, nGrids, spp) = sampleTable rng w
+          n = round (wImgWd w) * round (wImgHt w)
+          fl = flattenObjects objs
+          len xs = fromIntegral (length xs)   -- (a function binding: used at four list types)
+      withRecords 24 (fSpheres fl)   pokeSphere   $ \ps ->
+        withRecords 56 (fTriangles fl) pokeTriangle $ \pt ->
+        withRecords 48 (fMaterials fl) pokeMaterial $ \pm ->
+        withRecords 48 (wLights w)     pokeLight    $ \pl ->
+          check "rt_build_scene" err =<< c_rt_build ctx ps (len (fSpheres fl)) pt (len (fTriangles fl))
+                                                     pm (len (fMaterials fl)) pl (len (wLights w))
+      withCamera w $ \pc -> check "rt_set_camera" err =<< c_rt_camera ctx pc
+      withArray f6 $ \p -> check "rt_set_samples" err =<< c_rt_samples ctx p (fromIntegral nGrids) (fromIntegral spp)
+      allocaArray (3 * n) $ \out -> do
+        check "rt_render" err =<< c_rt_render ctx 0 out nullPtr nullPtr
+        toColors n out
+{-# NOINLINE renderGPUDeviceTree #-}
 
 -- | The same frame rendered on the first n GPUs of the node (tiles t mod n, RCCL gather on GPU 0).
 renderMultiGPU :: Int -> PureMT -> World -> [Color]
